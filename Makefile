@@ -1,0 +1,43 @@
+# rtcore-mi355x — builds the product library, the CPU oracle (test infrastructure) and the C++ host.
+#   make            -> raytracer_amd/lib/librtcore.so, oracle/liboracle.so, build/rt_host
+#   make lib|oracle|host|clean
+HIPCC     ?= /opt/rocm/bin/hipcc
+ARCH      ?= gfx950
+# strict IEEE f32 on the device: no contraction, correctly rounded div/sqrt, denormals kept
+HIPFLAGS  ?= --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math \
+             -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -Wall -Wno-unused-function
+CSRC      := raytracer_amd/csrc
+LIB       := raytracer_amd/lib/librtcore.so
+OBJS      := build/rt_api.o build/rt_build.o build/rt_trace.o build/rt_scene.o
+
+all: lib oracle host
+
+lib: $(LIB)
+
+build/%.o: $(CSRC)/%.hip $(CSRC)/rt_internal.h $(CSRC)/rt_device.h include/rtcore.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+build/rt_scene.o: $(CSRC)/rt_scene.cpp include/rtcore.h
+	@mkdir -p build
+	$(HIPCC) -std=c++17 -O2 -fPIC -ffp-contract=off -fno-fast-math -Wall -x c++ -c $< -o $@
+
+$(LIB): $(OBJS)
+	@mkdir -p raytracer_amd/lib
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+oracle:
+	$(MAKE) -C oracle
+
+host: build/rt_host
+
+build/rt_host: src/main.cpp include/rtcore.h $(LIB)
+	@mkdir -p build
+	g++ -std=c++17 -O2 -Wall -Wextra -Iinclude src/main.cpp -o $@ -Lraytracer_amd/lib -lrtcore \
+	    -Wl,-rpath,'$$ORIGIN/../raytracer_amd/lib' -Wl,-rpath-link,/opt/rocm/lib
+
+clean:
+	rm -rf build raytracer_amd/lib/librtcore.so
+	$(MAKE) -C oracle clean
+
+.PHONY: all lib oracle host clean

@@ -1,0 +1,215 @@
+/*
+ * rtcore.h — C ABI of the MI355X-native ray-tracing core (librtcore.so).
+ *
+ * Drop-in boundary for the two hot paths of 31415Hacker/RayTracer.  The
+ * reference has no FFI; the seam is its data contract, crossed twice:
+ *   build side : loadObj() mesh arrays            web/script.js:198-203
+ *                -> buildLBVH(mesh, 1)            web/script.js:285-513 (call site :729)
+ *                -> flattenForSSBO()              web/script.js:526-561
+ *   render side: bind group 0 + 176-byte uniforms web/compute.wgsl:4-22, web/script.js:798-810,899-930
+ *                -> one dispatch of cs_main       web/compute.wgsl:413-446, web/script.js:936-945
+ * Every entry point names the reference interface it replaces.
+ *
+ * Conventions: plain C types only; 0 = success, negative = error (message through
+ * rt_last_error, valid until the next call on the same context); inputs are copied
+ * during the call; outputs are caller-allocated; a context is not thread-safe (calls are
+ * serialised by the caller, like the reference's single JS thread); one context drives
+ * one GPU (one process per GPU; multi-GPU sharding is done by the host with RCCL, see
+ * the *_device entry points and INTEGRATION.md).
+ *
+ * There is NO CPU fallback behind this ABI: every compute entry point fails with
+ * RT_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef RTCORE_H
+#define RTCORE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+enum {
+  RT_OK = 0,
+  RT_ERR_INVALID = -1,      /* bad argument / call order */
+  RT_ERR_NO_DEVICE = -2,    /* HIP runtime or device unavailable */
+  RT_ERR_HIP = -3,          /* a HIP call failed (see rt_last_error) */
+  RT_ERR_IO = -4,           /* file / parse error */
+  RT_ERR_LIMIT = -5,        /* scene exceeds an encoding limit (F11: v1 node indices < 2^24) */
+  RT_ERR_INTERNAL = -6      /* a kernel reported an internal failure (e.g. bounded spin expired) */
+};
+
+/* ------------------------------------------------------------------ context */
+typedef struct rt_ctx rt_ctx;
+
+/* Replaces: adapter/device acquisition, web/script.js:706-715.
+ * backend must be "hip" (NULL = "hip"); device_ids/n_devices: exactly one device id
+ * (NULL/0 = device 0). */
+int         rt_create(rt_ctx** out, const char* backend, const int* device_ids, int n_devices);
+void        rt_destroy(rt_ctx* ctx);
+const char* rt_last_error(const rt_ctx* ctx);
+int         rt_abi_version(void);
+
+/* ------------------------------------------------------------------ scene input (host side, no GPU needed) */
+/* OBJ/MTL ingest with tiny_obj_loader v2.0.0 semantics (reference: /tiny_obj_loader.h:638,
+ * float parser :954-1122, index fix-up :867-907, quad split along the shorter diagonal
+ * :1701-1813); replaces loadObj, web/script.js:164-204.  Output arrays follow the loadObj
+ * return contract (script.js:198-203) plus texcoords / per-face material ids. */
+typedef struct rt_mesh rt_mesh;
+typedef struct rt_mesh_view {
+  const float*    positions;  uint32_t n_vert;   /* 3 floats each */
+  const float*    normals;    uint32_t n_nor;    /* 3 floats each (one dummy (0,0,0) entry if the file has none) */
+  const float*    texcoords;  uint32_t n_tex;    /* 2 floats each (one dummy (0,0) entry if the file has none) */
+  const uint32_t* vert_idx;                      /* 3 per triangle */
+  const uint32_t* nor_idx;                       /* 3 per triangle */
+  const uint32_t* tex_idx;                       /* 3 per triangle */
+  const int32_t*  material_ids;                  /* 1 per triangle, -1 = none */
+  uint32_t        n_tri;
+  uint32_t        n_materials;
+} rt_mesh_view;
+typedef struct rt_material {                     /* subset of tinyobj::material_t (tiny_obj_loader.h:188-247) */
+  char  name[128];
+  float diffuse[3];                              /* Kd */
+  float emission[3];                             /* Ke */
+  float dissolve;                                /* d / 1-Tr */
+  int   illum;
+  char  diffuse_texname[256];                    /* map_Kd */
+  char  bump_texname[256];                       /* map_Bump / bump */
+} rt_material;
+
+int  rt_mesh_load_obj(const char* obj_path, const char* mtl_search_dir /* NULL = dir of obj */,
+                      rt_mesh** out, char* err, size_t err_len);
+int  rt_mesh_parse_obj(const char* obj_text, size_t obj_len, const char* mtl_text /* or NULL */, size_t mtl_len,
+                       rt_mesh** out, char* err, size_t err_len);
+int  rt_mesh_view_get(const rt_mesh* m, rt_mesh_view* out);
+int  rt_mesh_material(const rt_mesh* m, uint32_t i, rt_material* out);
+void rt_mesh_free(rt_mesh* m);
+
+/* Replaces normalizeMesh, web/script.js:207-227 (in place; double math, f32 store). */
+int  rt_normalize_mesh(float* positions, uint32_t n_vert);
+
+/* Replaces updateCamera + basis + TRS sliders + invert4 + udata packing,
+ * web/script.js:591-612, 880-896, 136-154, 30-133, 899-929.  out44 = the 176-byte block
+ * of web/compute.wgsl:4-13 (cameraPos@0 lightPos@4 camRight@8 camUp@12 camForward@16
+ * model(inverse TRS)@20 resolution@36 time@38, float indices). */
+typedef struct rt_camera {
+  double pos[3];         /* script.js:4  default (0,0,5) */
+  double yaw, pitch;     /* script.js:5-6 */
+  double scale[3];       /* sliders scaleX/Y/Z, default 1 */
+  double rot_deg[3];     /* sliders rotX/Y/Z in degrees, default 0 (rotX gets -pi, script.js:148) */
+  double translate[3];   /* sliders posX/Y/Z, default 0 */
+  uint32_t width, height;
+  float  time;           /* the reference always uploads 0 */
+} rt_camera;
+void rt_camera_default(rt_camera* cam, uint32_t width, uint32_t height);
+int  rt_make_uniforms(const rt_camera* cam, float out44[44]);
+
+/* ------------------------------------------------------------------ hot path 1: LBVH build */
+/* Replaces the makeBuf uploads of the raw mesh (script.js:571-578): copies the loadObj
+ * arrays to the device. */
+int rt_set_mesh(rt_ctx* ctx, const float* positions, uint32_t n_vert, const float* normals, uint32_t n_nor,
+                const uint32_t* vert_idx, const uint32_t* nor_idx, uint32_t n_tri);
+
+typedef struct rt_build_stats {
+  float ms_bounds, ms_morton, ms_sort, ms_tree, ms_refit, ms_pack, ms_total;  /* hipEvent times */
+  uint32_t n_tri, n_nodes;
+  uint64_t algorithmic_bytes;   /* 560 B x n_tri */
+} rt_build_stats;
+
+/* Replaces buildLBVH(raw, 1) + flattenForSSBO (script.js:729-730) with the Morton LBVH the
+ * reference only sketched (web/morton_compute.wgsl, compiled but never dispatched — F4):
+ * centroid bounds -> 30-bit Morton -> stable onesweep radix sort -> Karras radix tree ->
+ * atomic bottom-up refit -> flat node / triangle buffers. */
+int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out /* may be NULL */);
+
+/* Introspection for parity tests (device -> caller-allocated host arrays). */
+int rt_get_bounds(rt_ctx* ctx, float bmin[3], float inv_extent[3]);   /* `Bounds` uniform, morton_compute.wgsl:3-6 */
+int rt_get_morton(rt_ctx* ctx, uint32_t* codes /* [T], triangle order of the input */);
+int rt_get_tri_order(rt_ctx* ctx, uint32_t* order /* [T]: BVH-order position -> input triangle */);
+int rt_get_counts(rt_ctx* ctx, uint32_t* n_tri, uint32_t* n_nodes);
+int rt_get_nodes(rt_ctx* ctx, float* nodes /* [8*N], layout script.js:546-559 */);
+int rt_get_triangles(rt_ctx* ctx, float* tri_pos /* [12*T] */, float* tri_nor /* [12*T] */); /* script.js:527-545 */
+
+/* Replaces the bvh/tri makeBuf uploads (script.js:743-748): import an externally built flat
+ * BVH (e.g. the reference's SAH builder output, or a BVH cache file) in the v1 layout. */
+int rt_set_bvh(rt_ctx* ctx, const float* nodes, uint32_t n_nodes,
+               const float* tri_pos, const float* tri_nor, uint32_t n_tri);
+
+/* BVH cache file (what web/bvh-buffer.bin was meant to be):
+ * header-less little-endian f32: nodes[8N] then tri_pos[12T] then tri_nor[12T]; N = 2T-1. */
+int rt_save_bvh(rt_ctx* ctx, const char* path);
+int rt_load_bvh(rt_ctx* ctx, const char* path);
+
+/* ------------------------------------------------------------------ hot path 2: traversal + shading */
+enum { RT_MODE_PRIMARY = 0,   /* primary ray, N.L shading, no shadow rays (BASELINE cfg 1-2) */
+       RT_MODE_SHADOW  = 1,   /* primary + SOFT_SAMPLES shadow rays (cfg 3) */
+       RT_MODE_PT      = 2 }; /* full computeLighting_optimized (cfg 4) */
+enum { RT_LAYOUT_WIDE64 = 0,  /* default: 64-byte two-child records + precomputed triangle edges */
+       RT_LAYOUT_AOS32  = 1 };/* traverse the 32-byte interchange records directly (A/B baseline) */
+enum { RT_FLAG_COUNT_WORK = 1 }; /* also count box/triangle tests (slower; for parity + roofline bytes) */
+
+typedef struct rt_render_opts {
+  int32_t mode;           /* RT_MODE_* */
+  int32_t gi_samples;     /* compute.wgsl:26 (32) */
+  int32_t gi_bounces;     /* compute.wgsl:27 (3)  */
+  int32_t soft_samples;   /* compute.wgsl:25 (4)  */
+  int32_t max_stack;      /* compute.wgsl:259 (12); 2..32 */
+  int32_t layout;         /* RT_LAYOUT_* */
+  int32_t flags;          /* RT_FLAG_* */
+  int32_t stripe_rows;    /* image-space sharding: rows per stripe (16); 0 = whole image */
+  int32_t stripe_rank;    /* this context renders stripes s with s % stripe_world == stripe_rank */
+  int32_t stripe_world;
+} rt_render_opts;
+void rt_render_opts_default(rt_render_opts* o);
+
+typedef struct rt_render_stats {
+  uint64_t rays_primary, rays_shadow, rays_bounce;
+  uint64_t box_tests, tri_tests, hit_updates;   /* only with RT_FLAG_COUNT_WORK */
+  uint64_t pixels;
+  uint64_t stack_drops;                          /* only with RT_FLAG_COUNT_WORK */
+  float    ms_kernel;                            /* hipEvent time of the traversal kernel */
+} rt_render_stats;
+
+/* Replaces queue.writeBuffer(uniformBuf) + dispatchWorkgroups(ceil(w/16), ceil(h/16)) of
+ * cs_main (script.js:930-945).  rgba8 = the rgba8unorm storage texture (compute.wgsl:22,445),
+ * row 0 first.  hit_tri (BVH-order index of the primary hit, 0xFFFFFFFF = miss) and hit_t
+ * are extra outputs for parity (the reference returns neither).  Outputs may be NULL.
+ * With striping, only this rank's rows of the full-size host images are written. */
+int rt_render(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* opts,
+              uint8_t* rgba8 /* [4*w*h] */, uint32_t* hit_tri /* [w*h] */, float* hit_t /* [w*h] */,
+              rt_render_stats* out /* may be NULL */);
+
+/* Same, outputs in caller-provided DEVICE memory of this context's GPU, asynchronous on
+ * the context stream unless stats != NULL.  With striping the outputs are PACKED: local
+ * row = (stripe / stripe_world) * stripe_rows + row_in_stripe (rt_packed_rows gives the
+ * row count). */
+int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* opts,
+                     void* d_rgba8, void* d_hit_tri, void* d_hit_t, rt_render_stats* out);
+uint32_t rt_packed_rows(uint32_t height, int32_t stripe_rows, int32_t stripe_rank, int32_t stripe_world);
+/* De-interleave `world` packed stripe buffers (concatenated rank-major, each
+ * rows_per_rank x width x elem_bytes) into a full image; all pointers are device memory. */
+int rt_deinterleave_device(rt_ctx* ctx, const void* d_packed, void* d_image, uint32_t width, uint32_t height,
+                           uint32_t elem_bytes, int32_t stripe_rows, int32_t stripe_world, uint32_t rows_per_rank);
+
+/* ------------------------------------------------------------------ multi-GPU: BVH replication (host drives RCCL) */
+/* The flat buffers of a built/imported BVH as device memory, for ncclBroadcast by the host. */
+typedef struct rt_bvh_view {
+  void*    d_nodes;    uint64_t nodes_bytes;     /* 32 B x N */
+  void*    d_tri_pos;  uint64_t tri_pos_bytes;   /* 48 B x T */
+  void*    d_tri_nor;  uint64_t tri_nor_bytes;   /* 48 B x T */
+  uint32_t n_nodes, n_tri;
+} rt_bvh_view;
+int rt_bvh_view_get(rt_ctx* ctx, rt_bvh_view* out);
+/* Adopt caller-owned device buffers (filled by a broadcast) as this context's BVH and derive
+ * the traversal layout from them.  The caller keeps the three buffers alive. */
+int rt_bvh_adopt_device(rt_ctx* ctx, const rt_bvh_view* view);
+
+int rt_synchronize(rt_ctx* ctx);
+/* The hipStream_t the context launches on (as void*), so hosts can order their own work. */
+void* rt_stream(rt_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,106 @@
+/*
+ * rt_oracle.h — scalar CPU ORACLE for the rtcore hot paths.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This library is the checker, never the product: only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  librtcore.so (the product) never links,
+ * loads or calls anything in oracle/.
+ *
+ * PARITY UNPINNED BY THE REFERENCE: 31415Hacker/RayTracer has no tests, golden vectors
+ * or fixtures for this path, its WGSL cannot be compiled here, and
+ * executing its script.js was denied.  The oracle is therefore a line-by-
+ * line CPU restatement of the WGSL, pinned by hand-derived known answers
+ * (tests/test_oracle_known_answers.py) and by structural property tests.
+ *
+ * Restated sources (all under /root/reference):
+ *   web/morton_compute.wgsl:18-69   expandBits / quantize / main
+ *   web/compute.wgsl:68-446         fetchCachedNode … cs_main
+ *   web/script.js:207-227           normalizeMesh
+ *   web/script.js:526-561           flattenForSSBO (node + triangle buffer layout)
+ *   web/script.js:30-154,591-612,880-929   camera / TRS / invert4 / uniform packing
+ * Sort / Karras radix tree / refit have no reference code; they follow
+ * the definitions pinned there.
+ *
+ * Build: g++ -O2 -ffp-contract=off (no fast-math), see oracle/Makefile.
+ */
+#ifndef RT_ORACLE_H
+#define RT_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORC_MODE_PRIMARY = 0, ORC_MODE_SHADOW = 1, ORC_MODE_PT = 2 };
+
+typedef struct orc_render_opts {
+  int32_t mode;          /* ORC_MODE_* */
+  int32_t gi_samples;    /* compute.wgsl:26 GI_SAMPLES (32); also drives the shadow stratification grid */
+  int32_t gi_bounces;    /* compute.wgsl:27 GI_BOUNCES (3) */
+  int32_t soft_samples;  /* compute.wgsl:25 SOFT_SAMPLES (4) */
+  int32_t max_stack;     /* compute.wgsl:259 MAX_STACK (12), <= 64 */
+  int32_t row_begin;     /* rows [row_begin,row_end) step row_step are rendered; others untouched */
+  int32_t row_end;
+  int32_t row_step;
+  int32_t n_threads;     /* std::thread row striping; 1 = scalar */
+} orc_render_opts;
+
+typedef struct orc_render_stats {
+  uint64_t rays_primary, rays_shadow, rays_bounce;
+  uint64_t box_tests;    /* V: (ray,node) pairs whose box is tested, each counted once */
+  uint64_t tri_tests;    /* K: triangles fetched in leaves */
+  uint64_t hit_updates;  /* H: closer-hit updates (normal fetches) */
+  uint64_t pixels;       /* P: pixels written */
+  uint64_t stack_drops;  /* far children dropped because the stack was full (F9) */
+  double   seconds;
+} orc_render_stats;
+
+/* web/morton_compute.wgsl:18-31 */
+uint32_t orc_expand_bits(uint32_t v);
+uint32_t orc_quantize(float x);
+/* web/compute.wgsl:135-149 */
+uint32_t orc_hash_u32(uint32_t seed);
+float    orc_rand2(float sx, float sy);
+/* implementation-pinned transcendental kernels (DESIGN.md "numerics contract") */
+void  orc_sincos(float theta, float* s, float* c);
+float orc_pow(float x, float y);
+
+/* web/script.js:207-227 — in place */
+void orc_normalize_mesh(float* pos, uint32_t n_vert);
+
+/* min / 1/(max-min) of triangle centroids (0 where extent is 0) */
+void orc_centroid_bounds(const float* pos, const uint32_t* vidx, uint32_t n_tri,
+                         float bmin[3], float inv_extent[3]);
+/* web/morton_compute.wgsl:33-69 */
+void orc_morton(const float* pos, const uint32_t* vidx, uint32_t n_tri,
+                const float bmin[3], const float inv_extent[3], uint32_t* codes);
+/* stable sort of (code, index) */
+void orc_sort(const uint32_t* codes, uint32_t n_tri, uint32_t* sorted_codes, uint32_t* order);
+/* Karras radix tree over sorted codes. Node ids: internal i -> i, leaf j -> (T-1)+j.
+ * child0/child1 have T-1 entries; parent has 2T-1 entries (parent[0] = -1). */
+void orc_karras(const uint32_t* sorted_codes, uint32_t n_tri,
+                int32_t* child0, int32_t* child1, int32_t* parent);
+/* Whole build: bounds -> morton -> sort -> tree -> refit -> flat buffers.
+ * nodes: 8 floats per node, (2T-1) nodes, layout of web/script.js:546-559.
+ * tri_pos/tri_nor: 12 floats per triangle (3 x vec4, w = 0), BVH order (script.js:527-545).
+ * codes (unsorted) and order may be NULL. */
+void orc_build_lbvh(const float* pos, uint32_t n_vert, const float* nor, uint32_t n_nor,
+                    const uint32_t* vidx, const uint32_t* nidx, uint32_t n_tri,
+                    float* nodes, float* tri_pos, float* tri_nor,
+                    uint32_t* codes, uint32_t* order, double* seconds);
+
+/* web/script.js:30-154,591-612,880-929: the 44 uniform floats.
+ * sliders = {scaleX,scaleY,scaleZ, rotX,rotY,rotZ (degrees), posX,posY,posZ} */
+void orc_make_uniforms(const double cam_pos[3], double yaw, double pitch,
+                       const double sliders[9], uint32_t width, uint32_t height,
+                       float time_value, float out44[44]);
+
+/* web/compute.wgsl:413-446 cs_main over the selected rows.
+ * rgba8: 4*w*h bytes; hit_tri: w*h (0xFFFFFFFF = miss, else BVH-order triangle index of the
+ * primary hit); hit_t: w*h (1e20 on miss).  Any output may be NULL. */
+int orc_render(const float* nodes, uint32_t n_nodes, const float* tri_pos, const float* tri_nor,
+               uint32_t n_tri, const float uniforms[44], const orc_render_opts* opts,
+               uint8_t* rgba8, uint32_t* hit_tri, float* hit_t, orc_render_stats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

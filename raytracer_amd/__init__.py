@@ -1,0 +1,248 @@
+"""raytracer_amd — host-side mirror of the reference's JS driver (web/script.js) over the
+C ABI of librtcore.so (include/rtcore.h).  Names follow the reference: load_obj (loadObj
+:164), normalize_mesh (:207), generate_test_scene (:639), build_lbvh (buildLBVH :285),
+flatten_for_ssbo (:526), make_uniforms (udata packing :899-929), render (frame() :865).
+
+All compute runs in the HIP library; there is no Python or CPU compute path here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._abi import (FLAG_COUNT_WORK, LAYOUT_AOS32, LAYOUT_WIDE64, MODE_PRIMARY, MODE_PT, MODE_SHADOW)  # noqa: F401
+
+_L = _abi.load()          # raises ImportError when the HIP extension is not built
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"rtcore error {code}: {msg}")
+        self.code = code
+
+
+class Mesh:
+    """The loadObj() return contract (script.js:198-203) + texcoords / material ids."""
+
+    def __init__(self, positions, normals, vert_idx, norm_idx, texcoords=None, tex_idx=None, material_ids=None, materials=()):
+        self.positions = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        self.normals = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+        self.vert_idx = np.ascontiguousarray(vert_idx, np.uint32).reshape(-1)
+        self.norm_idx = np.ascontiguousarray(norm_idx, np.uint32).reshape(-1)
+        self.texcoords = None if texcoords is None else np.ascontiguousarray(texcoords, np.float32).reshape(-1, 2)
+        self.tex_idx = None if tex_idx is None else np.ascontiguousarray(tex_idx, np.uint32).reshape(-1)
+        self.material_ids = None if material_ids is None else np.ascontiguousarray(material_ids, np.int32)
+        self.materials = list(materials)
+
+    @property
+    def n_tri(self):
+        return self.vert_idx.size // 3
+
+
+def _mesh_from_handle(h):
+    try:
+        v = _abi.MeshView()
+        rc = _L.rt_mesh_view_get(h, C.byref(v))
+        if rc != 0:
+            raise RtError(rc, "rt_mesh_view_get")
+        arr = lambda p, n, dt: np.ctypeslib.as_array(p, shape=(n,)).astype(dt, copy=True) if n else np.zeros(0, dt)
+        mats = []
+        for i in range(v.n_materials):
+            m = _abi.Material()
+            _L.rt_mesh_material(h, i, C.byref(m))
+            mats.append(dict(name=m.name.decode(), diffuse=tuple(m.diffuse), emission=tuple(m.emission), dissolve=m.dissolve,
+                             illum=m.illum, map_Kd=m.diffuse_texname.decode(), map_Bump=m.bump_texname.decode()))
+        return Mesh(arr(v.positions, 3 * v.n_vert, np.float32), arr(v.normals, 3 * v.n_nor, np.float32),
+                    arr(v.vert_idx, 3 * v.n_tri, np.uint32), arr(v.nor_idx, 3 * v.n_tri, np.uint32),
+                    arr(v.texcoords, 2 * v.n_tex, np.float32), arr(v.tex_idx, 3 * v.n_tri, np.uint32),
+                    arr(v.material_ids, v.n_tri, np.int32), mats)
+    finally:
+        _L.rt_mesh_free(h)
+
+
+def load_obj(path, mtl_dir=None):
+    """loadObj (script.js:164-204) with tiny_obj_loader parsing semantics."""
+    h = C.c_void_p()
+    err = C.create_string_buffer(512)
+    rc = _L.rt_mesh_load_obj(str(path).encode(), None if mtl_dir is None else str(mtl_dir).encode(), C.byref(h), err, 512)
+    if rc != 0:
+        raise RtError(rc, err.value.decode())
+    return _mesh_from_handle(h)
+
+
+def parse_obj(obj_text, mtl_text=None):
+    ob = obj_text.encode() if isinstance(obj_text, str) else bytes(obj_text)
+    mb = None if mtl_text is None else (mtl_text.encode() if isinstance(mtl_text, str) else bytes(mtl_text))
+    h = C.c_void_p()
+    err = C.create_string_buffer(512)
+    rc = _L.rt_mesh_parse_obj(ob, len(ob), mb, 0 if mb is None else len(mb), C.byref(h), err, 512)
+    if rc != 0:
+        raise RtError(rc, err.value.decode())
+    return _mesh_from_handle(h)
+
+
+def normalize_mesh(mesh):
+    """normalizeMesh (script.js:207-227), in place on mesh.positions."""
+    p = mesh.positions
+    rc = _L.rt_normalize_mesh(p.ctypes.data_as(C.c_void_p), p.shape[0])
+    if rc != 0:
+        raise RtError(rc, "rt_normalize_mesh")
+    return mesh
+
+
+def generate_test_scene():
+    """generateTestScene (script.js:639-675): the 2-triangle quad with +Z normals."""
+    return Mesh(np.float32([[-1, -1, 0], [1, -1, 0], [1, 1, 0], [-1, 1, 0]]), np.float32([[0, 0, 1]] * 4),
+                np.uint32([0, 1, 2, 0, 2, 3]), np.uint32([0, 1, 2, 0, 2, 3]))
+
+
+def make_uniforms(width, height, cam_pos=(0.0, 0.0, 5.0), yaw=0.0, pitch=0.0, scale=(1.0, 1.0, 1.0),
+                  rot_deg=(0.0, 0.0, 0.0), translate=(0.0, 0.0, 0.0), time=0.0):
+    """The 44 uniform floats of compute.wgsl:4-13 as frame() packs them (script.js:880-929)."""
+    cam = _abi.Camera()
+    _L.rt_camera_default(C.byref(cam), width, height)
+    cam.pos[:] = cam_pos
+    cam.yaw, cam.pitch = yaw, pitch
+    cam.scale[:] = scale
+    cam.rot_deg[:] = rot_deg
+    cam.translate[:] = translate
+    cam.time = time
+    out = np.zeros(44, np.float32)
+    rc = _L.rt_make_uniforms(C.byref(cam), out.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise RtError(rc, "rt_make_uniforms")
+    return out
+
+
+def render_opts(mode=MODE_PT, gi_samples=32, gi_bounces=3, soft_samples=4, max_stack=12, layout=LAYOUT_WIDE64, flags=0,
+                stripe_rows=0, stripe_rank=0, stripe_world=1):
+    return _abi.RenderOpts(mode, gi_samples, gi_bounces, soft_samples, max_stack, layout, flags, stripe_rows, stripe_rank,
+                           stripe_world)
+
+
+def packed_rows(height, stripe_rows, rank, world):
+    return int(_L.rt_packed_rows(height, stripe_rows, rank, world))
+
+
+def _vp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One GPU. Mirrors the page-lifetime state of the reference (device, buffers, pipelines)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        ids = (C.c_int * 1)(device)
+        rc = _L.rt_create(C.byref(self._h), b"hip", ids, 1)
+        if rc != 0:
+            raise RtError(rc, _L.rt_last_error(None).decode())
+        self.device = device
+
+    def close(self):
+        if self._h:
+            _L.rt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RtError(rc, _L.rt_last_error(self._h).decode())
+
+    # ---- hot path 1
+    def set_mesh(self, mesh):
+        self._chk(_L.rt_set_mesh(self._h, _vp(mesh.positions), mesh.positions.shape[0], _vp(mesh.normals),
+                                 mesh.normals.shape[0], _vp(mesh.vert_idx), _vp(mesh.norm_idx), mesh.n_tri))
+
+    def build_lbvh(self):
+        st = _abi.BuildStats()
+        self._chk(_L.rt_build_lbvh(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def counts(self):
+        t, n = C.c_uint32(), C.c_uint32()
+        self._chk(_L.rt_get_counts(self._h, C.byref(t), C.byref(n)))
+        return t.value, n.value
+
+    def bounds(self):
+        b, i = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        self._chk(_L.rt_get_bounds(self._h, _vp(b), _vp(i)))
+        return b, i
+
+    def morton(self):
+        c = np.zeros(self.counts()[0], np.uint32)
+        self._chk(_L.rt_get_morton(self._h, _vp(c)))
+        return c
+
+    def tri_order(self):
+        o = np.zeros(self.counts()[0], np.uint32)
+        self._chk(_L.rt_get_tri_order(self._h, _vp(o)))
+        return o
+
+    def flatten_for_ssbo(self):
+        """{triPos, triNor, bvhData} exactly as flattenForSSBO returns them (script.js:560)."""
+        T, N = self.counts()
+        nodes, tp, tn = np.zeros((N, 8), np.float32), np.zeros((T, 3, 4), np.float32), np.zeros((T, 3, 4), np.float32)
+        self._chk(_L.rt_get_nodes(self._h, _vp(nodes)))
+        self._chk(_L.rt_get_triangles(self._h, _vp(tp), _vp(tn)))
+        return dict(triPos=tp, triNor=tn, bvhData=nodes)
+
+    def set_bvh(self, nodes, tri_pos, tri_nor):
+        nodes = np.ascontiguousarray(nodes, np.float32).reshape(-1, 8)
+        tp = np.ascontiguousarray(tri_pos, np.float32).reshape(-1, 12)
+        tn = np.ascontiguousarray(tri_nor, np.float32).reshape(-1, 12)
+        self._chk(_L.rt_set_bvh(self._h, _vp(nodes), nodes.shape[0], _vp(tp), _vp(tn), tp.shape[0]))
+
+    def save_bvh(self, path):
+        self._chk(_L.rt_save_bvh(self._h, str(path).encode()))
+
+    def load_bvh(self, path):
+        self._chk(_L.rt_load_bvh(self._h, str(path).encode()))
+
+    # ---- hot path 2
+    def render(self, uniforms, opts=None, want=("rgba8", "hit_tri", "hit_t")):
+        """One frame() (script.js:865-945) into host arrays. Returns (outputs, stats)."""
+        opts = opts or render_opts()
+        U = np.ascontiguousarray(uniforms, np.float32)
+        w, h = int(U[36]), int(U[37])
+        out = {}
+        if "rgba8" in want: out["rgba8"] = np.zeros((h, w, 4), np.uint8)
+        if "hit_tri" in want: out["hit_tri"] = np.full((h, w), 0xFFFFFFFF, np.uint32)
+        if "hit_t" in want: out["hit_t"] = np.zeros((h, w), np.float32)
+        st = _abi.RenderStats()
+        self._chk(_L.rt_render(self._h, _vp(U), C.byref(opts), _vp(out.get("rgba8")), _vp(out.get("hit_tri")),
+                               _vp(out.get("hit_t")), C.byref(st)))
+        return out, st.as_dict()
+
+    def render_device(self, uniforms, opts, d_rgba8=0, d_hit_tri=0, d_hit_t=0, want_stats=True):
+        """Outputs into caller-owned device memory (integer addresses, e.g. torch .data_ptr())."""
+        U = np.ascontiguousarray(uniforms, np.float32)
+        st = _abi.RenderStats()
+        self._chk(_L.rt_render_device(self._h, _vp(U), C.byref(opts), C.c_void_p(d_rgba8 or None), C.c_void_p(d_hit_tri or None),
+                                      C.c_void_p(d_hit_t or None), C.byref(st) if want_stats else None))
+        return st.as_dict() if want_stats else None
+
+    def deinterleave_device(self, d_packed, d_image, width, height, elem_bytes, stripe_rows, world, rows_per_rank):
+        self._chk(_L.rt_deinterleave_device(self._h, C.c_void_p(d_packed), C.c_void_p(d_image), width, height, elem_bytes,
+                                            stripe_rows, world, rows_per_rank))
+
+    # ---- multi-GPU plumbing
+    def bvh_view(self):
+        v = _abi.BvhView()
+        self._chk(_L.rt_bvh_view_get(self._h, C.byref(v)))
+        return v
+
+    def adopt_bvh_device(self, d_nodes, d_tri_pos, d_tri_nor, n_nodes, n_tri):
+        v = _abi.BvhView(d_nodes, 32 * n_nodes, d_tri_pos, 48 * n_tri, d_tri_nor, 48 * n_tri, n_nodes, n_tri)
+        self._chk(_L.rt_bvh_adopt_device(self._h, C.byref(v)))
+
+    def synchronize(self):
+        self._chk(_L.rt_synchronize(self._h))
+
+    def stream(self):
+        return _L.rt_stream(self._h)

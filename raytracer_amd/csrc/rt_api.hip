@@ -1,0 +1,531 @@
+// rt_api.hip — the C ABI of include/rtcore.h on top of the gfx950 kernels.
+// One context = one GPU + one HIP stream.  No CPU fallback exists: every compute entry
+// point needs a usable HIP device.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_internal.h"
+
+namespace {
+std::string g_create_error;
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  hipError_t ensure(size_t count) {
+    if (count <= n && p) return hipSuccess;
+    if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+    if (count == 0) return hipSuccess;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    if (e == hipSuccess) n = count;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+}  // namespace
+
+struct rt_ctx {
+  int device = 0;
+  int n_cu = 256;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[8] = {};
+  std::string err;
+
+  // mesh (loadObj contract)
+  DevBuf<float> pos, nor;
+  DevBuf<uint32_t> vidx, nidx;
+  uint32_t n_vert = 0, n_nor = 0, n_tri_mesh = 0;
+
+  // build scratch
+  DevBuf<uint32_t> bounds_enc, codes, keys_a, keys_b, vals_a, vals_b, hist, tile_status, tile_counter, visit, words;
+  DevBuf<float> bounds_f;
+  DevBuf<int32_t> child, parent;
+  bool built = false;      // codes / order valid
+
+  // BVH
+  RtBvhDev bvh;
+  DevBuf<float> own_nodes, own_tri_pos, own_tri_nor;
+  DevBuf<float4> wide, tri_pre;
+  bool have_bvh = false;
+
+  // render scratch
+  DevBuf<uint32_t> r_tile_counter;
+  DevBuf<unsigned long long> r_stats;
+  DevBuf<uint8_t> o_rgba;
+  DevBuf<uint32_t> o_tri;
+  DevBuf<float> o_t;
+
+  int fail(int code, const std::string& msg) { err = msg; return code; }
+  int hipfail(const char* what, hipError_t e) {
+    err = std::string(what) + ": " + hipGetErrorString(e);
+    return RT_ERR_HIP;
+  }
+};
+
+#define HIPCHK(expr)                                             \
+  do {                                                           \
+    hipError_t e_ = (expr);                                      \
+    if (e_ != hipSuccess) return ctx->hipfail(#expr, e_);        \
+  } while (0)
+
+namespace {
+struct DeviceGuard {   // makes the context's device current for the duration of a call
+  int prev = -1;
+  explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; (void)hipSetDevice(dev); }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+int finish_bvh(rt_ctx* ctx) {   // derive the traversal layout from the interchange buffers
+  RtBvhDev& b = ctx->bvh;
+  b.leaf_shift = 23;
+  b.n_wide = b.n_nodes;   // imported trees may number internal nodes anywhere in [0, N)
+  HIPCHK(ctx->wide.ensure((size_t)b.n_wide * 4));
+  HIPCHK(ctx->tri_pre.ensure((size_t)b.n_tri * 3));
+  HIPCHK(ctx->words.ensure(4));
+  b.wide = ctx->wide.p; b.tri_pre = ctx->tri_pre.p;
+  HIPCHK(hipMemsetAsync(ctx->words.p, 0, 4 * sizeof(uint32_t), ctx->stream));
+  rt_launch_pack_impl(b, ctx->words.p + 0, ctx->words.p + 1, ctx->stream);
+  HIPCHK(hipGetLastError());
+  uint32_t w[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(w, ctx->words.p, sizeof(w), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (w[1] & 2u) return ctx->fail(RT_ERR_LIMIT, "leaf start/count exceeds the WIDE64 reference encoding (start < 2^23, count <= 256)");
+  if (w[1] & 4u) return ctx->fail(RT_ERR_INVALID, "node buffer has an out-of-range child index");
+  b.root_ref = w[0];
+  ctx->have_bvh = true;
+  return RT_OK;
+}
+}  // namespace
+
+// ================================================================ context
+extern "C" int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+extern "C" int rt_create(rt_ctx** out, const char* backend, const int* device_ids, int n_devices) {
+  if (!out) return RT_ERR_INVALID;
+  *out = nullptr;
+  if (backend && std::strcmp(backend, "hip") != 0) {
+    g_create_error = "only backend \"hip\" exists (the CPU oracle is test infrastructure, not a backend)";
+    return RT_ERR_INVALID;
+  }
+  if (n_devices > 1) { g_create_error = "one context drives one GPU; create one context (process) per device"; return RT_ERR_INVALID; }
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    g_create_error = std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    return RT_ERR_NO_DEVICE;
+  }
+  const int dev = (device_ids && n_devices == 1) ? device_ids[0] : 0;
+  if (dev < 0 || dev >= count) { g_create_error = "device id out of range"; return RT_ERR_INVALID; }
+  rt_ctx* ctx = new rt_ctx();
+  ctx->device = dev;
+  if ((e = hipSetDevice(dev)) != hipSuccess) { g_create_error = hipGetErrorString(e); delete ctx; return RT_ERR_HIP; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+  if ((e = hipStreamCreate(&ctx->stream)) != hipSuccess) { g_create_error = hipGetErrorString(e); delete ctx; return RT_ERR_HIP; }
+  for (auto& ev : ctx->ev) (void)hipEventCreate(&ev);
+  *out = ctx;
+  return RT_OK;
+}
+
+extern "C" void rt_destroy(rt_ctx* ctx) {
+  if (!ctx) return;
+  DeviceGuard g(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  ctx->pos.release(); ctx->nor.release(); ctx->vidx.release(); ctx->nidx.release();
+  ctx->bounds_enc.release(); ctx->codes.release(); ctx->keys_a.release(); ctx->keys_b.release();
+  ctx->vals_a.release(); ctx->vals_b.release(); ctx->hist.release(); ctx->tile_status.release();
+  ctx->tile_counter.release(); ctx->visit.release(); ctx->words.release(); ctx->bounds_f.release();
+  ctx->child.release(); ctx->parent.release();
+  ctx->own_nodes.release(); ctx->own_tri_pos.release(); ctx->own_tri_nor.release();
+  ctx->wide.release(); ctx->tri_pre.release();
+  ctx->r_tile_counter.release(); ctx->r_stats.release(); ctx->o_rgba.release(); ctx->o_tri.release(); ctx->o_t.release();
+  for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+extern "C" int rt_synchronize(rt_ctx* ctx) {
+  if (!ctx) return RT_ERR_INVALID;
+  DeviceGuard g(ctx->device);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return RT_OK;
+}
+extern "C" void* rt_stream(rt_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+// ================================================================ hot path 1
+extern "C" int rt_set_mesh(rt_ctx* ctx, const float* positions, uint32_t n_vert, const float* normals, uint32_t n_nor,
+                           const uint32_t* vert_idx, const uint32_t* nor_idx, uint32_t n_tri) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (!positions || !normals || !vert_idx || !nor_idx || n_vert == 0 || n_nor == 0 || n_tri == 0)
+    return ctx->fail(RT_ERR_INVALID, "rt_set_mesh: empty mesh or NULL array");
+  if (n_tri > (1u << 30)) return ctx->fail(RT_ERR_LIMIT, "rt_set_mesh: more than 2^30 triangles");
+  for (size_t i = 0; i < (size_t)n_tri * 3; ++i)   // a wild index would fault the GPU: check on the host
+    if (vert_idx[i] >= n_vert || nor_idx[i] >= n_nor) return ctx->fail(RT_ERR_INVALID, "rt_set_mesh: index out of range");
+  DeviceGuard g(ctx->device);
+  HIPCHK(ctx->pos.ensure((size_t)n_vert * 3));
+  HIPCHK(ctx->nor.ensure((size_t)n_nor * 3));
+  HIPCHK(ctx->vidx.ensure((size_t)n_tri * 3));
+  HIPCHK(ctx->nidx.ensure((size_t)n_tri * 3));
+  HIPCHK(hipMemcpyAsync(ctx->pos.p, positions, sizeof(float) * 3 * n_vert, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->nor.p, normals, sizeof(float) * 3 * n_nor, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->vidx.p, vert_idx, sizeof(uint32_t) * 3 * n_tri, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->nidx.p, nor_idx, sizeof(uint32_t) * 3 * n_tri, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->n_vert = n_vert; ctx->n_nor = n_nor; ctx->n_tri_mesh = n_tri;
+  ctx->built = false;
+  return RT_OK;
+}
+
+extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (ctx->n_tri_mesh == 0) return ctx->fail(RT_ERR_INVALID, "rt_build_lbvh: call rt_set_mesh first");
+  const uint32_t T = ctx->n_tri_mesh, N = 2 * T - 1;
+  if (N > (1u << 24))
+    return ctx->fail(RT_ERR_LIMIT, "rt_build_lbvh: v1 node records store indices as f32 values, exact only below 2^24 (SURVEY F11)");
+  DeviceGuard g(ctx->device);
+  hipStream_t s = ctx->stream;
+  HIPCHK(ctx->bounds_enc.ensure(8)); HIPCHK(ctx->bounds_f.ensure(8));
+  HIPCHK(ctx->codes.ensure(T)); HIPCHK(ctx->keys_a.ensure(T)); HIPCHK(ctx->keys_b.ensure(T));
+  HIPCHK(ctx->vals_a.ensure(T)); HIPCHK(ctx->vals_b.ensure(T));
+  HIPCHK(ctx->hist.ensure(4 * 256)); HIPCHK(ctx->tile_status.ensure(rt_sort_status_words(T)));
+  HIPCHK(ctx->tile_counter.ensure(4)); HIPCHK(ctx->words.ensure(4));
+  HIPCHK(ctx->child.ensure(2 * (size_t)(T > 1 ? T - 1 : 1))); HIPCHK(ctx->parent.ensure(N));
+  HIPCHK(ctx->visit.ensure(T > 1 ? T - 1 : 1));
+  HIPCHK(ctx->own_nodes.ensure((size_t)N * 8)); HIPCHK(ctx->own_tri_pos.ensure((size_t)T * 12));
+  HIPCHK(ctx->own_tri_nor.ensure((size_t)T * 12));
+
+  RtBuildBuffers b;
+  b.pos = ctx->pos.p; b.nor = ctx->nor.p; b.vidx = ctx->vidx.p; b.nidx = ctx->nidx.p; b.n_tri = T;
+  b.bounds_enc = ctx->bounds_enc.p; b.bounds_f = ctx->bounds_f.p; b.codes = ctx->codes.p;
+  b.keys_a = ctx->keys_a.p; b.keys_b = ctx->keys_b.p; b.vals_a = ctx->vals_a.p; b.vals_b = ctx->vals_b.p;
+  b.hist = ctx->hist.p; b.tile_status = ctx->tile_status.p; b.tile_counter = ctx->tile_counter.p;
+  b.err_flag = ctx->words.p + 2; b.child = ctx->child.p; b.parent = ctx->parent.p; b.visit = ctx->visit.p;
+  b.n_sort_tiles = rt_sort_tile_count(T);
+
+  HIPCHK(hipMemsetAsync(ctx->words.p, 0, 4 * sizeof(uint32_t), s));
+  HIPCHK(hipEventRecord(ctx->ev[0], s));
+  rt_launch_bounds(b, s);
+  HIPCHK(hipEventRecord(ctx->ev[1], s));
+  rt_launch_morton(b, s);
+  HIPCHK(hipEventRecord(ctx->ev[2], s));
+  rt_launch_sort(b, s);
+  HIPCHK(hipEventRecord(ctx->ev[3], s));
+  rt_launch_karras(b, s);
+  HIPCHK(hipEventRecord(ctx->ev[4], s));
+  rt_launch_refit(b, ctx->own_nodes.p, ctx->own_tri_pos.p, ctx->own_tri_nor.p, s);
+  HIPCHK(hipEventRecord(ctx->ev[5], s));
+  HIPCHK(hipGetLastError());
+  uint32_t errw = 0;
+  HIPCHK(hipMemcpyAsync(&errw, ctx->words.p + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (errw) return ctx->fail(RT_ERR_INTERNAL, "rt_build_lbvh: radix-sort look-back spin limit expired");
+
+  ctx->bvh = RtBvhDev();
+  ctx->bvh.nodes = ctx->own_nodes.p; ctx->bvh.tri_pos = ctx->own_tri_pos.p; ctx->bvh.tri_nor = ctx->own_tri_nor.p;
+  ctx->bvh.n_nodes = N; ctx->bvh.n_tri = T; ctx->bvh.owns_interchange = true;
+  HIPCHK(hipEventRecord(ctx->ev[6], s));
+  int rc = finish_bvh(ctx);
+  if (rc != RT_OK) return rc;
+  HIPCHK(hipEventRecord(ctx->ev[7], s));
+  HIPCHK(hipEventSynchronize(ctx->ev[7]));
+  ctx->built = true;
+  if (out) {
+    std::memset(out, 0, sizeof(*out));
+    (void)hipEventElapsedTime(&out->ms_bounds, ctx->ev[0], ctx->ev[1]);
+    (void)hipEventElapsedTime(&out->ms_morton, ctx->ev[1], ctx->ev[2]);
+    (void)hipEventElapsedTime(&out->ms_sort, ctx->ev[2], ctx->ev[3]);
+    (void)hipEventElapsedTime(&out->ms_tree, ctx->ev[3], ctx->ev[4]);
+    (void)hipEventElapsedTime(&out->ms_refit, ctx->ev[4], ctx->ev[5]);
+    (void)hipEventElapsedTime(&out->ms_pack, ctx->ev[6], ctx->ev[7]);
+    out->ms_total = out->ms_bounds + out->ms_morton + out->ms_sort + out->ms_tree + out->ms_refit + out->ms_pack;
+    out->n_tri = T; out->n_nodes = N;
+    out->algorithmic_bytes = 560ull * T;
+  }
+  return RT_OK;
+}
+
+#define NEED_BUILT()  if (!ctx) return RT_ERR_INVALID; if (!ctx->built) return ctx->fail(RT_ERR_INVALID, "no LBVH has been built in this context")
+#define NEED_BVH()    if (!ctx) return RT_ERR_INVALID; if (!ctx->have_bvh) return ctx->fail(RT_ERR_INVALID, "no BVH: call rt_build_lbvh / rt_set_bvh / rt_bvh_adopt_device")
+
+extern "C" int rt_get_bounds(rt_ctx* ctx, float bmin[3], float inv_extent[3]) {
+  NEED_BUILT();
+  DeviceGuard g(ctx->device);
+  float f[8];
+  HIPCHK(hipMemcpy(f, ctx->bounds_f.p, sizeof(f), hipMemcpyDeviceToHost));
+  for (int k = 0; k < 3; ++k) { bmin[k] = f[k]; inv_extent[k] = f[4 + k]; }
+  return RT_OK;
+}
+extern "C" int rt_get_morton(rt_ctx* ctx, uint32_t* codes) {
+  NEED_BUILT();
+  DeviceGuard g(ctx->device);
+  HIPCHK(hipMemcpy(codes, ctx->codes.p, sizeof(uint32_t) * ctx->bvh.n_tri, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+extern "C" int rt_get_tri_order(rt_ctx* ctx, uint32_t* order) {
+  NEED_BUILT();
+  DeviceGuard g(ctx->device);
+  HIPCHK(hipMemcpy(order, ctx->vals_a.p, sizeof(uint32_t) * ctx->bvh.n_tri, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+extern "C" int rt_get_counts(rt_ctx* ctx, uint32_t* n_tri, uint32_t* n_nodes) {
+  NEED_BVH();
+  if (n_tri) *n_tri = ctx->bvh.n_tri;
+  if (n_nodes) *n_nodes = ctx->bvh.n_nodes;
+  return RT_OK;
+}
+extern "C" int rt_get_nodes(rt_ctx* ctx, float* nodes) {
+  NEED_BVH();
+  DeviceGuard g(ctx->device);
+  HIPCHK(hipMemcpy(nodes, ctx->bvh.nodes, sizeof(float) * 8 * (size_t)ctx->bvh.n_nodes, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+extern "C" int rt_get_triangles(rt_ctx* ctx, float* tri_pos, float* tri_nor) {
+  NEED_BVH();
+  DeviceGuard g(ctx->device);
+  if (tri_pos) HIPCHK(hipMemcpy(tri_pos, ctx->bvh.tri_pos, sizeof(float) * 12 * (size_t)ctx->bvh.n_tri, hipMemcpyDeviceToHost));
+  if (tri_nor) HIPCHK(hipMemcpy(tri_nor, ctx->bvh.tri_nor, sizeof(float) * 12 * (size_t)ctx->bvh.n_tri, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+namespace {
+// host-side structural validation of an imported v1 node buffer: a bad index would fault the GPU
+int validate_nodes(rt_ctx* ctx, const float* nodes, uint32_t n_nodes, uint32_t n_tri) {
+  for (uint32_t i = 0; i < n_nodes; ++i) {
+    const float a = nodes[8 * (size_t)i + 3], b = nodes[8 * (size_t)i + 7];
+    if (b < 0.0f) {
+      const double start = a, cnt = -(double)b;
+      if (!(start >= 0) || start != (double)(int64_t)start || cnt != (double)(int64_t)cnt || start + cnt > (double)n_tri)
+        return ctx->fail(RT_ERR_INVALID, "imported BVH: leaf range outside the triangle buffer at node " + std::to_string(i));
+    } else {
+      if (!(a >= 0) || !(b >= 0) || a >= (double)n_nodes || b >= (double)n_nodes || a != (double)(int64_t)a || b != (double)(int64_t)b)
+        return ctx->fail(RT_ERR_INVALID, "imported BVH: child index out of range at node " + std::to_string(i));
+    }
+  }
+  return RT_OK;
+}
+}  // namespace
+
+extern "C" int rt_set_bvh(rt_ctx* ctx, const float* nodes, uint32_t n_nodes, const float* tri_pos, const float* tri_nor, uint32_t n_tri) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (!nodes || !tri_pos || !tri_nor || n_nodes == 0 || n_tri == 0) return ctx->fail(RT_ERR_INVALID, "rt_set_bvh: empty input");
+  if (n_nodes > (1u << 24)) return ctx->fail(RT_ERR_LIMIT, "rt_set_bvh: v1 node records are exact only below 2^24 nodes (SURVEY F11)");
+  int rc = validate_nodes(ctx, nodes, n_nodes, n_tri);
+  if (rc != RT_OK) return rc;
+  DeviceGuard g(ctx->device);
+  ctx->have_bvh = false; ctx->built = false;
+  HIPCHK(ctx->own_nodes.ensure((size_t)n_nodes * 8));
+  HIPCHK(ctx->own_tri_pos.ensure((size_t)n_tri * 12));
+  HIPCHK(ctx->own_tri_nor.ensure((size_t)n_tri * 12));
+  HIPCHK(hipMemcpyAsync(ctx->own_nodes.p, nodes, sizeof(float) * 8 * (size_t)n_nodes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->own_tri_pos.p, tri_pos, sizeof(float) * 12 * (size_t)n_tri, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->own_tri_nor.p, tri_nor, sizeof(float) * 12 * (size_t)n_tri, hipMemcpyHostToDevice, ctx->stream));
+  ctx->bvh = RtBvhDev();
+  ctx->bvh.nodes = ctx->own_nodes.p; ctx->bvh.tri_pos = ctx->own_tri_pos.p; ctx->bvh.tri_nor = ctx->own_tri_nor.p;
+  ctx->bvh.n_nodes = n_nodes; ctx->bvh.n_tri = n_tri;
+  return finish_bvh(ctx);
+}
+
+extern "C" int rt_save_bvh(rt_ctx* ctx, const char* path) {
+  NEED_BVH();
+  if (!path) return ctx->fail(RT_ERR_INVALID, "rt_save_bvh: NULL path");
+  const size_t N = ctx->bvh.n_nodes, T = ctx->bvh.n_tri;
+  std::vector<float> buf(8 * N + 24 * T);
+  int rc = rt_get_nodes(ctx, buf.data());
+  if (rc != RT_OK) return rc;
+  rc = rt_get_triangles(ctx, buf.data() + 8 * N, buf.data() + 8 * N + 12 * T);
+  if (rc != RT_OK) return rc;
+  FILE* f = std::fopen(path, "wb");
+  if (!f) return ctx->fail(RT_ERR_IO, std::string("cannot open for writing: ") + path);
+  const size_t w = std::fwrite(buf.data(), sizeof(float), buf.size(), f);
+  std::fclose(f);
+  if (w != buf.size()) return ctx->fail(RT_ERR_IO, std::string("short write: ") + path);
+  return RT_OK;
+}
+
+extern "C" int rt_load_bvh(rt_ctx* ctx, const char* path) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (!path) return ctx->fail(RT_ERR_INVALID, "rt_load_bvh: NULL path");
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return ctx->fail(RT_ERR_IO, std::string("cannot open: ") + path);
+  std::fseek(f, 0, SEEK_END);
+  const long sz = std::ftell(f);
+  std::fseek(f, 0, SEEK_SET);
+  // 32 B x (2T-1) + 96 B x T = 160 T - 32
+  if (sz <= 0 || (sz + 32) % 160 != 0) { std::fclose(f); return ctx->fail(RT_ERR_IO, "not a BVH cache file (size is not 160*T-32 bytes)"); }
+  const size_t T = (size_t)(sz + 32) / 160, N = 2 * T - 1;
+  std::vector<float> buf((size_t)sz / 4);
+  const size_t r = std::fread(buf.data(), 1, (size_t)sz, f);
+  std::fclose(f);
+  if (r != (size_t)sz) return ctx->fail(RT_ERR_IO, "short read");
+  return rt_set_bvh(ctx, buf.data(), (uint32_t)N, buf.data() + 8 * N, buf.data() + 8 * N + 12 * T, (uint32_t)T);
+}
+
+// ================================================================ multi-GPU plumbing
+extern "C" int rt_bvh_view_get(rt_ctx* ctx, rt_bvh_view* out) {
+  NEED_BVH();
+  if (!out) return RT_ERR_INVALID;
+  out->d_nodes = ctx->bvh.nodes; out->nodes_bytes = 32ull * ctx->bvh.n_nodes;
+  out->d_tri_pos = ctx->bvh.tri_pos; out->tri_pos_bytes = 48ull * ctx->bvh.n_tri;
+  out->d_tri_nor = ctx->bvh.tri_nor; out->tri_nor_bytes = 48ull * ctx->bvh.n_tri;
+  out->n_nodes = ctx->bvh.n_nodes; out->n_tri = ctx->bvh.n_tri;
+  return RT_OK;
+}
+
+extern "C" int rt_bvh_adopt_device(rt_ctx* ctx, const rt_bvh_view* v) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (!v || !v->d_nodes || !v->d_tri_pos || !v->d_tri_nor || v->n_nodes == 0 || v->n_tri == 0)
+    return ctx->fail(RT_ERR_INVALID, "rt_bvh_adopt_device: incomplete view");
+  if (v->nodes_bytes < 32ull * v->n_nodes || v->tri_pos_bytes < 48ull * v->n_tri || v->tri_nor_bytes < 48ull * v->n_tri)
+    return ctx->fail(RT_ERR_INVALID, "rt_bvh_adopt_device: buffers smaller than the counts imply");
+  if (v->n_nodes > (1u << 24)) return ctx->fail(RT_ERR_LIMIT, "v1 node records are exact only below 2^24 nodes (SURVEY F11)");
+  DeviceGuard g(ctx->device);
+  ctx->have_bvh = false; ctx->built = false;
+  ctx->bvh = RtBvhDev();
+  ctx->bvh.nodes = static_cast<float*>(v->d_nodes);
+  ctx->bvh.tri_pos = static_cast<float*>(v->d_tri_pos);
+  ctx->bvh.tri_nor = static_cast<float*>(v->d_tri_nor);
+  ctx->bvh.n_nodes = v->n_nodes; ctx->bvh.n_tri = v->n_tri; ctx->bvh.owns_interchange = false;
+  return finish_bvh(ctx);   // the pack kernel range-checks every child / leaf index on the device
+}
+
+// ================================================================ hot path 2
+extern "C" void rt_render_opts_default(rt_render_opts* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->mode = RT_MODE_PT; o->gi_samples = 32; o->gi_bounces = 3; o->soft_samples = 4; o->max_stack = 12;   // compute.wgsl:25-27,259
+  o->layout = RT_LAYOUT_WIDE64; o->stripe_rows = 0; o->stripe_rank = 0; o->stripe_world = 1;
+}
+
+extern "C" uint32_t rt_packed_rows(uint32_t height, int32_t stripe_rows, int32_t rank, int32_t world) {
+  if (stripe_rows <= 0 || world <= 1) return height;
+  const uint32_t sr = (uint32_t)stripe_rows;
+  const uint32_t n_stripes = (height + sr - 1) / sr;
+  uint32_t rows = 0;
+  for (uint32_t s = (uint32_t)rank; s < n_stripes; s += (uint32_t)world) {
+    const uint32_t y0 = s * sr;
+    rows += (y0 + sr <= height) ? sr : (height - y0);
+  }
+  return rows;
+}
+
+namespace {
+int check_opts(rt_ctx* ctx, const rt_render_opts* o) {
+  if (!o) return ctx->fail(RT_ERR_INVALID, "render opts are NULL");
+  if (o->mode < RT_MODE_PRIMARY || o->mode > RT_MODE_PT) return ctx->fail(RT_ERR_INVALID, "bad mode");
+  if (o->max_stack < 2 || o->max_stack > 32) return ctx->fail(RT_ERR_INVALID, "max_stack must be in [2,32]");
+  if (o->gi_samples < 1 || o->gi_samples > 4096 || o->gi_bounces < 0 || o->gi_bounces > 64 || o->soft_samples < 1 || o->soft_samples > 64)
+    return ctx->fail(RT_ERR_INVALID, "sample counts out of range");
+  if (o->layout != RT_LAYOUT_WIDE64 && o->layout != RT_LAYOUT_AOS32) return ctx->fail(RT_ERR_INVALID, "bad layout");
+  if (o->stripe_rows < 0 || (o->stripe_rows > 0 && (o->stripe_rows % 8 != 0)))
+    return ctx->fail(RT_ERR_INVALID, "stripe_rows must be a multiple of 8 (tile height)");
+  if (o->stripe_rows > 0 && (o->stripe_world < 1 || o->stripe_rank < 0 || o->stripe_rank >= o->stripe_world))
+    return ctx->fail(RT_ERR_INVALID, "bad stripe rank/world");
+  return RT_OK;
+}
+}  // namespace
+
+extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* opts, void* d_rgba8, void* d_hit_tri,
+                                void* d_hit_t, rt_render_stats* out) {
+  NEED_BVH();
+  if (!uniforms) return ctx->fail(RT_ERR_INVALID, "uniforms are NULL");
+  int rc = check_opts(ctx, opts);
+  if (rc != RT_OK) return rc;
+  const float fw = uniforms[36], fh = uniforms[37];
+  if (!(fw >= 1.0f) || !(fh >= 1.0f) || fw > 65536.0f || fh > 65536.0f) return ctx->fail(RT_ERR_INVALID, "resolution out of range");
+  DeviceGuard g(ctx->device);
+  RtRenderParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.nodes = ctx->bvh.nodes; p.tri_pos = ctx->bvh.tri_pos; p.tri_nor = ctx->bvh.tri_nor;
+  p.wide = ctx->bvh.wide; p.tri_pre = ctx->bvh.tri_pre; p.root_ref = ctx->bvh.root_ref; p.leaf_shift = ctx->bvh.leaf_shift;
+  std::memcpy(p.U, uniforms, sizeof(float) * 44);
+  p.mode = opts->mode; p.gi_samples = opts->gi_samples; p.gi_bounces = opts->gi_bounces; p.soft_samples = opts->soft_samples;
+  p.max_stack = opts->max_stack;
+  p.width = (uint32_t)fw; p.height = (uint32_t)fh;
+  const bool striped = opts->stripe_rows > 0 && opts->stripe_world > 1;
+  p.stripe_rows = striped ? opts->stripe_rows : 0; p.stripe_rank = striped ? opts->stripe_rank : 0;
+  p.stripe_world = striped ? opts->stripe_world : 1;
+  p.local_rows = rt_packed_rows(p.height, p.stripe_rows, p.stripe_rank, p.stripe_world);
+  p.tiles_x = (p.width + 7) / 8;
+  p.n_tiles = p.tiles_x * ((p.local_rows + 7) / 8);
+  p.rgba8 = static_cast<uint8_t*>(d_rgba8); p.hit_tri = static_cast<uint32_t*>(d_hit_tri); p.hit_t = static_cast<float*>(d_hit_t);
+  HIPCHK(ctx->r_tile_counter.ensure(1));
+  HIPCHK(ctx->r_stats.ensure(8));
+  p.tile_counter = ctx->r_tile_counter.p; p.stats = ctx->r_stats.p;
+  hipStream_t s = ctx->stream;
+  HIPCHK(hipMemsetAsync(p.tile_counter, 0, sizeof(uint32_t), s));
+  HIPCHK(hipMemsetAsync(p.stats, 0, sizeof(unsigned long long) * 8, s));
+  if (p.n_tiles > 0) {
+    if (out) HIPCHK(hipEventRecord(ctx->ev[0], s));
+    rt_launch_render(p, opts->layout, (opts->flags & RT_FLAG_COUNT_WORK) != 0, ctx->n_cu, s);
+    HIPCHK(hipGetLastError());
+    if (out) HIPCHK(hipEventRecord(ctx->ev[1], s));
+  }
+  if (out) {
+    unsigned long long st[8];
+    HIPCHK(hipMemcpyAsync(st, p.stats, sizeof(st), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    std::memset(out, 0, sizeof(*out));
+    out->rays_primary = st[0]; out->rays_shadow = st[1]; out->rays_bounce = st[2];
+    out->box_tests = st[3]; out->tri_tests = st[4]; out->hit_updates = st[5]; out->pixels = st[6]; out->stack_drops = st[7];
+    if (p.n_tiles > 0) (void)hipEventElapsedTime(&out->ms_kernel, ctx->ev[0], ctx->ev[1]);
+  }
+  return RT_OK;
+}
+
+extern "C" int rt_render(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* opts, uint8_t* rgba8, uint32_t* hit_tri,
+                         float* hit_t, rt_render_stats* out) {
+  NEED_BVH();
+  if (!uniforms) return ctx->fail(RT_ERR_INVALID, "uniforms are NULL");
+  int rc = check_opts(ctx, opts);
+  if (rc != RT_OK) return rc;
+  const float fw = uniforms[36], fh = uniforms[37];
+  if (!(fw >= 1.0f) || !(fh >= 1.0f) || fw > 65536.0f || fh > 65536.0f) return ctx->fail(RT_ERR_INVALID, "resolution out of range");
+  const uint32_t w = (uint32_t)fw, h = (uint32_t)fh;
+  const bool striped = opts->stripe_rows > 0 && opts->stripe_world > 1;
+  const uint32_t rows = rt_packed_rows(h, striped ? opts->stripe_rows : 0, opts->stripe_rank, striped ? opts->stripe_world : 1);
+  const size_t n = (size_t)rows * w;
+  DeviceGuard g(ctx->device);
+  if (rgba8) HIPCHK(ctx->o_rgba.ensure(n * 4));
+  if (hit_tri) HIPCHK(ctx->o_tri.ensure(n));
+  if (hit_t) HIPCHK(ctx->o_t.ensure(n));
+  rt_render_stats st;
+  rc = rt_render_device(ctx, uniforms, opts, rgba8 ? ctx->o_rgba.p : nullptr, hit_tri ? ctx->o_tri.p : nullptr,
+                        hit_t ? ctx->o_t.p : nullptr, &st);
+  if (rc != RT_OK) return rc;
+  if (out) *out = st;
+  auto fetch = [&](void* host, const void* dev, size_t elem) -> int {
+    if (!host || n == 0) return RT_OK;
+    if (!striped) { HIPCHK(hipMemcpy(host, dev, n * elem, hipMemcpyDeviceToHost)); return RT_OK; }
+    std::vector<unsigned char> tmp(n * elem);
+    HIPCHK(hipMemcpy(tmp.data(), dev, n * elem, hipMemcpyDeviceToHost));
+    const uint32_t sr = (uint32_t)opts->stripe_rows;
+    for (uint32_t lr = 0; lr < rows; ++lr) {
+      const uint32_t y = ((lr / sr) * (uint32_t)opts->stripe_world + (uint32_t)opts->stripe_rank) * sr + lr % sr;
+      std::memcpy(static_cast<unsigned char*>(host) + (size_t)y * w * elem, tmp.data() + (size_t)lr * w * elem, (size_t)w * elem);
+    }
+    return RT_OK;
+  };
+  if ((rc = fetch(rgba8, ctx->o_rgba.p, 4)) != RT_OK) return rc;
+  if ((rc = fetch(hit_tri, ctx->o_tri.p, 4)) != RT_OK) return rc;
+  if ((rc = fetch(hit_t, ctx->o_t.p, 4)) != RT_OK) return rc;
+  return RT_OK;
+}
+
+extern "C" int rt_deinterleave_device(rt_ctx* ctx, const void* d_packed, void* d_image, uint32_t width, uint32_t height,
+                                      uint32_t elem_bytes, int32_t stripe_rows, int32_t stripe_world, uint32_t rows_per_rank) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (!d_packed || !d_image || width == 0 || height == 0 || stripe_rows <= 0 || stripe_world < 1 || (elem_bytes != 1 && elem_bytes != 4))
+    return ctx->fail(RT_ERR_INVALID, "rt_deinterleave_device: bad argument");
+  const uint32_t need = rt_packed_rows(height, stripe_rows, 0, stripe_world);   // rank 0 always holds the most rows
+  if (rows_per_rank < need) return ctx->fail(RT_ERR_INVALID, "rt_deinterleave_device: rows_per_rank too small");
+  DeviceGuard g(ctx->device);
+  rt_launch_deinterleave(d_packed, d_image, width, height, elem_bytes, stripe_rows, stripe_world, rows_per_rank, ctx->stream);
+  HIPCHK(hipGetLastError());
+  return RT_OK;
+}

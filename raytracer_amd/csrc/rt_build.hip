@@ -1,0 +1,440 @@
+// rt_build.hip — hot path 1: Morton LBVH build on gfx950 (wave64).
+//
+// Pipeline (the reference only has the Morton shader,
+// web/morton_compute.wgsl, and never dispatches it — F4):
+//   k_bounds*      centroid min/max reduction (order-independent => bit-exact)
+//   k_morton       morton_compute.wgsl:33-69, one thread per triangle
+//   k_sort_*       onesweep LSD radix sort, 4 x 8-bit digits, (key, payload) pairs, STABLE:
+//                  one global histogram pass, then per digit a single pass with
+//                  chained-scan decoupled look-back, wave64 ballot/popcount ranking and an
+//                  LDS-staged scatter
+//   k_karras       Karras 2012 radix tree, one thread per internal node, ties broken by index
+//   k_refit        one thread per leaf: emit BVH-ordered triangle buffers + leaf record, then
+//                  climb; the second arrival at a node (atomic counter) unions the children
+//   k_pack_*       derive the traversal layout (64-byte two-child records, hoisted edges)
+// All kernels are HBM-bound integer/min-max work: coalesced 4-16 B/lane accesses, LDS staging,
+// no MFMA.
+#include "rt_device.h"
+#include "rt_internal.h"
+
+namespace {
+
+constexpr int BLK = 256;
+constexpr int RADIX = 256;
+constexpr int SORT_KPT = 16;                       // keys per thread
+constexpr int SORT_TILE = BLK * SORT_KPT;          // 4096 keys per tile
+constexpr uint32_t ST_AGG = 1u << 30, ST_INCL = 2u << 30, ST_MASK = (1u << 30) - 1u;
+constexpr uint32_t SPIN_LIMIT = 1u << 24;          // bounded look-back spin (error flag instead of a hang)
+
+inline int grid_for(uint32_t n, int per_block, int cap = 2048) {
+  long g = ((long)n + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+RT_DEV V3 load_vtx(const float* pos, uint32_t i) { return v3(pos[3 * (size_t)i + 0], pos[3 * (size_t)i + 1], pos[3 * (size_t)i + 2]); }
+// web/morton_compute.wgsl:52 — (p0 + p1 + p2) / 3.0, left to right, true division
+RT_DEV V3 tri_centroid(const float* pos, const uint32_t* vidx, uint32_t t) {
+  V3 p0 = load_vtx(pos, vidx[3 * (size_t)t + 0]), p1 = load_vtx(pos, vidx[3 * (size_t)t + 1]), p2 = load_vtx(pos, vidx[3 * (size_t)t + 2]);
+  return ((p0 + p1) + p2) / 3.0f;
+}
+
+RT_DEV uint32_t wave_min_u32(uint32_t v) {
+  for (int o = 32; o >= 1; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o));
+  return v;
+}
+RT_DEV uint32_t wave_max_u32(uint32_t v) {
+  for (int o = 32; o >= 1; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
+  return v;
+}
+
+// ---------------------------------------------------------------- centroid bounds
+__global__ void k_bounds_init(uint32_t* enc) {
+  if (threadIdx.x < 3) enc[threadIdx.x] = 0xFFFFFFFFu;
+  else if (threadIdx.x < 6) enc[threadIdx.x] = 0u;
+}
+
+__global__ __launch_bounds__(BLK) void k_bounds(const float* __restrict__ pos, const uint32_t* __restrict__ vidx,
+                                                uint32_t n_tri, uint32_t* __restrict__ enc) {
+  uint32_t mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u};
+  for (uint32_t t = blockIdx.x * BLK + threadIdx.x; t < n_tri; t += gridDim.x * BLK) {
+    V3 c = tri_centroid(pos, vidx, t);
+    uint32_t e[3] = {f2ord(c.x), f2ord(c.y), f2ord(c.z)};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { mn[k] = min(mn[k], e[k]); mx[k] = max(mx[k], e[k]); }
+  }
+  __shared__ uint32_t s[6][BLK / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    uint32_t a = wave_min_u32(mn[k]), b = wave_max_u32(mx[k]);
+    if (lane == 0) { s[k][wave] = a; s[3 + k][wave] = b; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    uint32_t v = s[k][0];
+    for (int w = 1; w < BLK / 64; ++w) v = (k < 3) ? min(v, s[k][w]) : max(v, s[k][w]);
+    if (k < 3) atomicMin(&enc[k], v); else atomicMax(&enc[k], v);
+  }
+}
+
+// `Bounds` uniform of morton_compute.wgsl:3-6; invExtent = 1/(max-min), 0 where the extent is 0
+__global__ void k_bounds_final(const uint32_t* enc, float* bounds_f) {
+  const int k = threadIdx.x;
+  if (k < 3) {
+    float lo = ord2f(enc[k]), hi = ord2f(enc[3 + k]);
+    float ext = hi - lo;
+    bounds_f[k] = lo;
+    bounds_f[4 + k] = (ext > 0.0f) ? (1.0f / ext) : 0.0f;
+  } else if (k == 3) { bounds_f[3] = 0.0f; bounds_f[7] = 0.0f; }
+}
+
+// ---------------------------------------------------------------- Morton codes
+__global__ __launch_bounds__(BLK) void k_morton(const float* __restrict__ pos, const uint32_t* __restrict__ vidx,
+                                                uint32_t n_tri, const float* __restrict__ bounds_f,
+                                                uint32_t* __restrict__ codes, uint32_t* __restrict__ keys,
+                                                uint32_t* __restrict__ vals) {
+  const V3 bmin = v3(bounds_f[0], bounds_f[1], bounds_f[2]), inv = v3(bounds_f[4], bounds_f[5], bounds_f[6]);
+  for (uint32_t t = blockIdx.x * BLK + threadIdx.x; t < n_tri; t += gridDim.x * BLK) {
+    V3 ctr = tri_centroid(pos, vidx, t);
+    V3 nrm = (ctr - bmin) * inv;                                          // :55
+    uint32_t code = (expand_bits(quantize10(nrm.x)) << 2) | (expand_bits(quantize10(nrm.y)) << 1) |
+                    expand_bits(quantize10(nrm.z));                      // :58-68
+    codes[t] = code; keys[t] = code; vals[t] = t;
+  }
+}
+
+// ---------------------------------------------------------------- onesweep radix sort
+__global__ __launch_bounds__(BLK) void k_sort_hist(const uint32_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[4][RADIX];
+  for (int i = threadIdx.x; i < 4 * RADIX; i += BLK) (&h[0][0])[i] = 0;
+  __syncthreads();
+  for (uint32_t i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) {
+    uint32_t k = keys[i];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) atomicAdd(&h[p][(k >> (8 * p)) & 255u], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 4 * RADIX; i += BLK) {
+    uint32_t v = (&h[0][0])[i];
+    if (v) atomicAdd(&hist[i], v);
+  }
+}
+
+// block-wide exclusive scan of one value per thread (BLK = 256 = 4 waves)
+RT_DEV uint32_t block_excl_scan(uint32_t v, uint32_t* s_wave /*[4]*/, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t t = (uint32_t)__shfl_up((int)inc, o);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < BLK / 64; ++w) { uint32_t x = s_wave[w]; if (w < wave) base += x; tot += x; }
+  if (total) *total = tot;
+  __syncthreads();
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(BLK) void k_sort_scan(uint32_t* hist) {   // 4 blocks: one per digit position
+  __shared__ uint32_t s_wave[BLK / 64];
+  uint32_t* h = hist + blockIdx.x * RADIX;
+  uint32_t v = h[threadIdx.x];
+  uint32_t ex = block_excl_scan(v, s_wave, nullptr);
+  h[threadIdx.x] = ex;
+}
+
+__global__ __launch_bounds__(BLK) void k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                  uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                  uint32_t n, int shift, const uint32_t* __restrict__ digit_base,
+                                                  uint32_t* status, uint32_t* tile_counter, uint32_t* err_flag) {
+  __shared__ uint32_t s_keys[SORT_TILE];
+  __shared__ uint32_t s_vals[SORT_TILE];
+  __shared__ uint32_t s_whist[BLK / 64][RADIX];
+  __shared__ uint32_t s_dstart[RADIX];
+  __shared__ uint32_t s_gbase[RADIX];
+  __shared__ uint32_t s_wave[BLK / 64];
+  __shared__ uint32_t s_tile;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // tile ids are handed out in start order, so every predecessor tile is already running:
+  // the look-back below cannot wait on a block that has not been scheduled.
+  if (tid == 0) s_tile = atomicAdd(tile_counter, 1u);
+  for (int i = tid; i < (BLK / 64) * RADIX; i += BLK) (&s_whist[0][0])[i] = 0;
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  const uint32_t base = tile * (uint32_t)SORT_TILE;
+  const uint32_t wbase = base + (uint32_t)wave * (64 * SORT_KPT);
+
+  uint32_t key[SORT_KPT], val[SORT_KPT], rank[SORT_KPT];
+#pragma unroll
+  for (int r = 0; r < SORT_KPT; ++r) {
+    uint32_t idx = wbase + r * 64 + lane;
+    bool valid = idx < n;
+    key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
+    val[r] = valid ? vals_in[idx] : 0u;
+  }
+  // wave-level stable ranking: peers = lanes holding the same digit (8 ballots), rank inside
+  // the peer group by popcount below the lane; the group leader bumps the wave's digit counter.
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int r = 0; r < SORT_KPT; ++r) {
+    const bool valid = (wbase + r * 64 + lane) < n;
+    const uint32_t d = (key[r] >> shift) & 255u;
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const unsigned long long bal = __ballot(bit);
+      peers &= bit ? bal : ~bal;
+    }
+    int leader = lane;
+    uint32_t prev = 0;
+    if (valid) {
+      leader = __ffsll((long long)peers) - 1;
+      if (lane == leader) prev = atomicAdd(&s_whist[wave][d], (uint32_t)__popcll(peers));
+    }
+    prev = (uint32_t)__shfl((int)prev, leader);
+    rank[r] = prev + (uint32_t)__popcll(peers & lt_mask);
+  }
+  __syncthreads();
+
+  // thread d owns digit d: per-wave exclusive offsets, tile total, look-back
+  uint32_t total = 0;
+  {
+    uint32_t run = 0;
+#pragma unroll
+    for (int w = 0; w < BLK / 64; ++w) { uint32_t c = s_whist[w][tid]; s_whist[w][tid] = run; run += c; }
+    total = run;
+  }
+  uint32_t* my_status = status + (size_t)tile * RADIX + tid;
+  __hip_atomic_store(my_status, (tile == 0 ? ST_INCL : ST_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t dstart = block_excl_scan(total, s_wave, nullptr);
+  uint32_t excl = 0;
+  if (tile > 0) {
+    uint32_t p = tile - 1, spins = 0;
+    for (;;) {
+      const uint32_t sw = __hip_atomic_load(status + (size_t)p * RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t f = sw >> 30;
+      if (f == 0) {
+        if (++spins > SPIN_LIMIT) { atomicOr(err_flag, 1u); break; }
+        __builtin_amdgcn_s_sleep(1);
+        continue;
+      }
+      excl += sw & ST_MASK;
+      if (f == 2 || p == 0) break;
+      --p;
+    }
+    __hip_atomic_store(my_status, ST_INCL | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  s_dstart[tid] = dstart;
+  s_gbase[tid] = digit_base[tid] + excl - dstart;
+  __syncthreads();
+
+  // LDS-staged scatter: tile-local sorted order first, then coalesced runs to HBM
+#pragma unroll
+  for (int r = 0; r < SORT_KPT; ++r) {
+    if ((wbase + r * 64 + lane) < n) {
+      const uint32_t d = (key[r] >> shift) & 255u;
+      const uint32_t pos = s_dstart[d] + s_whist[wave][d] + rank[r];
+      s_keys[pos] = key[r];
+      s_vals[pos] = val[r];
+    }
+  }
+  __syncthreads();
+  const uint32_t cnt = (n - base < (uint32_t)SORT_TILE) ? (n - base) : (uint32_t)SORT_TILE;
+#pragma unroll
+  for (int k = 0; k < SORT_KPT; ++k) {
+    const uint32_t i = tid + k * BLK;
+    if (i < cnt) {
+      const uint32_t kk = s_keys[i];
+      const uint32_t out = s_gbase[(kk >> shift) & 255u] + i;
+      keys_out[out] = kk;
+      vals_out[out] = s_vals[i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------- Karras radix tree
+// delta(i,j): common prefix of the augmented keys (code, index); -1 when j is out of range
+RT_DEV int kdelta(const uint32_t* __restrict__ k, int n, int i, uint32_t ki, int j) {
+  if (j < 0 || j >= n) return -1;
+  const uint32_t kj = k[j];
+  if (ki != kj) return __clz((int)(ki ^ kj));
+  return 32 + __clz((int)((uint32_t)i ^ (uint32_t)j));
+}
+
+__global__ __launch_bounds__(BLK) void k_karras(const uint32_t* __restrict__ k, uint32_t n_tri,
+                                                int32_t* __restrict__ child, int32_t* __restrict__ parent) {
+  const int n = (int)n_tri;
+  const int i = blockIdx.x * BLK + threadIdx.x;
+  if (i == 0) parent[0] = -1;
+  if (i >= n - 1) return;
+  const uint32_t ki = k[i];
+  const int d = (kdelta(k, n, i, ki, i + 1) - kdelta(k, n, i, ki, i - 1)) > 0 ? 1 : -1;
+  const int dmin = kdelta(k, n, i, ki, i - d);
+  int lmax = 2;
+  while (kdelta(k, n, i, ki, i + lmax * d) > dmin) lmax <<= 1;
+  int l = 0;
+  for (int t = lmax >> 1; t >= 1; t >>= 1)
+    if (kdelta(k, n, i, ki, i + (l + t) * d) > dmin) l += t;
+  const int j = i + l * d;
+  const int dnode = kdelta(k, n, i, ki, j);
+  int s = 0;
+  for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
+    if (kdelta(k, n, i, ki, i + (s + t) * d) > dnode) s += t;
+    if (t == 1) break;
+  }
+  const int gamma = i + s * d + min(d, 0);
+  const int lo = min(i, j), hi = max(i, j);
+  // node ids: internal k -> k, leaf k -> (T-1)+k
+  const int c0 = (lo == gamma) ? (n - 1) + gamma : gamma;
+  const int c1 = (hi == gamma + 1) ? (n - 1) + gamma + 1 : gamma + 1;
+  child[2 * i + 0] = c0; child[2 * i + 1] = c1;
+  parent[c0] = i; parent[c1] = i;
+}
+
+// ---------------------------------------------------------------- leaves + bottom-up refit
+__global__ __launch_bounds__(BLK) void k_refit(const float* __restrict__ pos, const float* __restrict__ nor,
+                                               const uint32_t* __restrict__ vidx, const uint32_t* __restrict__ nidx,
+                                               const uint32_t* __restrict__ order, uint32_t n_tri,
+                                               const int32_t* __restrict__ child, const int32_t* __restrict__ parent,
+                                               uint32_t* visit, float* nodes, float* __restrict__ tri_pos,
+                                               float* __restrict__ tri_nor) {
+  const uint32_t j = blockIdx.x * BLK + threadIdx.x;
+  if (j >= n_tri) return;
+  const uint32_t ti = order[j];
+  V3 p[3];
+  float4* tp = reinterpret_cast<float4*>(tri_pos) + (size_t)j * 3;
+  float4* tn = reinterpret_cast<float4*>(tri_nor) + (size_t)j * 3;
+#pragma unroll
+  for (int v = 0; v < 3; ++v) {                     // web/script.js:530-545
+    p[v] = load_vtx(pos, vidx[3 * (size_t)ti + v]);
+    V3 nn = load_vtx(nor, nidx[3 * (size_t)ti + v]);
+    tp[v] = make_float4(p[v].x, p[v].y, p[v].z, 0.0f);
+    tn[v] = make_float4(nn.x, nn.y, nn.z, 0.0f);
+  }
+  // true triangle bounds (web/script.js:309-316)
+  V3 mn = v3(fminf(fminf(p[0].x, p[1].x), p[2].x), fminf(fminf(p[0].y, p[1].y), p[2].y), fminf(fminf(p[0].z, p[1].z), p[2].z));
+  V3 mx = v3(fmaxf(fmaxf(p[0].x, p[1].x), p[2].x), fmaxf(fmaxf(p[0].y, p[1].y), p[2].y), fmaxf(fmaxf(p[0].z, p[1].z), p[2].z));
+  int cur = (int)(n_tri - 1) + (int)j;
+  float4* nd = reinterpret_cast<float4*>(nodes);
+  nd[2 * (size_t)cur + 0] = make_float4(mn.x, mn.y, mn.z, (float)j);      // A = tri_start (script.js:348,554)
+  nd[2 * (size_t)cur + 1] = make_float4(mx.x, mx.y, mx.z, -1.0f);         // B = -count
+  for (;;) {
+    const int par = parent[cur];
+    if (par < 0) break;
+    __threadfence();                                   // release this subtree's records (agent scope)
+    const uint32_t arrived = atomicAdd(&visit[par], 1u);
+    if (arrived == 0) break;                           // the sibling's thread will finish this node
+    __threadfence();                                   // acquire the sibling's record
+    const int c0 = child[2 * par + 0], c1 = child[2 * par + 1];
+    const int sib = (c0 == cur) ? c1 : c0;
+    const float4 s0 = nd[2 * (size_t)sib + 0], s1 = nd[2 * (size_t)sib + 1];
+    mn = v3(fminf(mn.x, s0.x), fminf(mn.y, s0.y), fminf(mn.z, s0.z));
+    mx = v3(fmaxf(mx.x, s1.x), fmaxf(mx.y, s1.y), fmaxf(mx.z, s1.z));
+    nd[2 * (size_t)par + 0] = make_float4(mn.x, mn.y, mn.z, (float)c0);   // indices as f32 values (F11)
+    nd[2 * (size_t)par + 1] = make_float4(mx.x, mx.y, mx.z, (float)c1);
+    cur = par;
+  }
+}
+
+// ---------------------------------------------------------------- traversal layout
+RT_DEV uint32_t make_ref(const float4 a, const float4 b, int node, int leaf_shift, uint32_t* err) {
+  if (b.w < 0.0f) {                                   // leaf test of fetchCachedNode, compute.wgsl:75
+    const uint32_t start = (uint32_t)sat_i32(a.w), count = (uint32_t)(-sat_i32(b.w));
+    const uint32_t max_start = (leaf_shift >= 31) ? 0x7FFFFFFFu : ((1u << leaf_shift) - 1u);
+    const uint32_t max_count = (leaf_shift >= 31) ? 1u : (1u << (31 - leaf_shift));
+    if (start > max_start || count < 1 || count > max_count) { atomicOr(err, 2u); return 0xFFFFFFFFu; }
+    return 0x80000000u | ((count - 1u) << leaf_shift) | start;
+  }
+  return (uint32_t)node;
+}
+
+__global__ __launch_bounds__(BLK) void k_pack_wide(const float* __restrict__ nodes, uint32_t n_nodes, float4* __restrict__ wide,
+                                                   uint32_t n_wide, int leaf_shift, uint32_t* root_ref, uint32_t* err) {
+  const uint32_t i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n_nodes) return;
+  const float4* nd = reinterpret_cast<const float4*>(nodes);
+  const float4 a = nd[2 * (size_t)i], b = nd[2 * (size_t)i + 1];
+  if (i == 0) *root_ref = make_ref(a, b, 0, leaf_shift, err);
+  if (b.w < 0.0f) return;
+  const int c0 = sat_i32(a.w), c1 = sat_i32(b.w);
+  if (i >= n_wide || c0 < 0 || c1 < 0 || (uint32_t)c0 >= n_nodes || (uint32_t)c1 >= n_nodes) { atomicOr(err, 4u); return; }
+  const float4 a0 = nd[2 * (size_t)c0], b0 = nd[2 * (size_t)c0 + 1];
+  const float4 a1 = nd[2 * (size_t)c1], b1 = nd[2 * (size_t)c1 + 1];
+  const uint32_t r0 = make_ref(a0, b0, c0, leaf_shift, err), r1 = make_ref(a1, b1, c1, leaf_shift, err);
+  wide[4 * (size_t)i + 0] = make_float4(a0.x, a0.y, a0.z, __uint_as_float(r0));
+  wide[4 * (size_t)i + 1] = make_float4(b0.x, b0.y, b0.z, __uint_as_float(r1));
+  wide[4 * (size_t)i + 2] = make_float4(a1.x, a1.y, a1.z, 0.0f);
+  wide[4 * (size_t)i + 3] = make_float4(b1.x, b1.y, b1.z, 0.0f);
+}
+
+__global__ __launch_bounds__(BLK) void k_pack_tris(const float* __restrict__ tri_pos, uint32_t n_tri, float4* __restrict__ tri_pre) {
+  const uint32_t t = blockIdx.x * BLK + threadIdx.x;
+  if (t >= n_tri) return;
+  const float4* tp = reinterpret_cast<const float4*>(tri_pos) + (size_t)t * 3;
+  const V3 v0 = xyz(tp[0]), v1 = xyz(tp[1]), v2 = xyz(tp[2]);
+  const V3 e1 = v1 - v0, e2 = v2 - v0;               // compute.wgsl:114-115 == :282 operands
+  const V3 ng = cross3(e1, e2);
+  tri_pre[3 * (size_t)t + 0] = make_float4(v0.x, v0.y, v0.z, ng.x);
+  tri_pre[3 * (size_t)t + 1] = make_float4(e1.x, e1.y, e1.z, ng.y);
+  tri_pre[3 * (size_t)t + 2] = make_float4(e2.x, e2.y, e2.z, ng.z);
+}
+
+}  // namespace
+
+uint32_t rt_sort_tile_count(uint32_t n) { return (n + SORT_TILE - 1) / SORT_TILE; }
+size_t rt_sort_status_words(uint32_t n) { return (size_t)4 * rt_sort_tile_count(n) * RADIX; }
+
+void rt_launch_bounds(const RtBuildBuffers& b, hipStream_t s) {
+  hipLaunchKernelGGL(k_bounds_init, dim3(1), dim3(64), 0, s, b.bounds_enc);
+  hipLaunchKernelGGL(k_bounds, dim3(grid_for(b.n_tri, BLK)), dim3(BLK), 0, s, b.pos, b.vidx, b.n_tri, b.bounds_enc);
+  hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(64), 0, s, b.bounds_enc, b.bounds_f);
+}
+
+void rt_launch_morton(const RtBuildBuffers& b, hipStream_t s) {
+  hipLaunchKernelGGL(k_morton, dim3(grid_for(b.n_tri, BLK)), dim3(BLK), 0, s, b.pos, b.vidx, b.n_tri, b.bounds_f, b.codes,
+                     b.keys_a, b.vals_a);
+}
+
+void rt_launch_sort(const RtBuildBuffers& b, hipStream_t s) {
+  const uint32_t n = b.n_tri, tiles = rt_sort_tile_count(n);
+  (void)hipMemsetAsync(b.hist, 0, sizeof(uint32_t) * 4 * RADIX, s);
+  (void)hipMemsetAsync(b.tile_status, 0, sizeof(uint32_t) * rt_sort_status_words(n), s);
+  (void)hipMemsetAsync(b.tile_counter, 0, sizeof(uint32_t) * 4, s);
+  hipLaunchKernelGGL(k_sort_hist, dim3(grid_for(n, BLK * 8)), dim3(BLK), 0, s, b.keys_a, n, b.hist);
+  hipLaunchKernelGGL(k_sort_scan, dim3(4), dim3(BLK), 0, s, b.hist);
+  uint32_t *ki = b.keys_a, *vi = b.vals_a, *ko = b.keys_b, *vo = b.vals_b;
+  for (int p = 0; p < 4; ++p) {
+    hipLaunchKernelGGL(k_onesweep, dim3(tiles), dim3(BLK), 0, s, ki, vi, ko, vo, n, 8 * p, b.hist + p * RADIX,
+                       b.tile_status + (size_t)p * tiles * RADIX, b.tile_counter + p, b.err_flag);
+    uint32_t* t;
+    t = ki; ki = ko; ko = t;
+    t = vi; vi = vo; vo = t;
+  }
+}
+
+void rt_launch_karras(const RtBuildBuffers& b, hipStream_t s) {
+  const uint32_t n_int = b.n_tri > 1 ? b.n_tri - 1 : 1;
+  hipLaunchKernelGGL(k_karras, dim3((n_int + BLK - 1) / BLK), dim3(BLK), 0, s, b.keys_a, b.n_tri, b.child, b.parent);
+}
+
+void rt_launch_refit(const RtBuildBuffers& b, float* nodes, float* tri_pos, float* tri_nor, hipStream_t s) {
+  if (b.n_tri > 1) (void)hipMemsetAsync(b.visit, 0, sizeof(uint32_t) * (b.n_tri - 1), s);
+  hipLaunchKernelGGL(k_refit, dim3((b.n_tri + BLK - 1) / BLK), dim3(BLK), 0, s, b.pos, b.nor, b.vidx, b.nidx, b.vals_a, b.n_tri,
+                     b.child, b.parent, b.visit, nodes, tri_pos, tri_nor);
+}
+
+// root_ref / err words live right behind the bounds words: see rt_api.hip (scratch[0], scratch[1])
+void rt_launch_pack_impl(const RtBvhDev& bvh, uint32_t* d_root_ref, uint32_t* d_err, hipStream_t s) {
+  hipLaunchKernelGGL(k_pack_wide, dim3((bvh.n_nodes + BLK - 1) / BLK), dim3(BLK), 0, s, bvh.nodes, bvh.n_nodes, bvh.wide,
+                     bvh.n_wide, bvh.leaf_shift, d_root_ref, d_err);
+  hipLaunchKernelGGL(k_pack_tris, dim3((bvh.n_tri + BLK - 1) / BLK), dim3(BLK), 0, s, bvh.tri_pos, bvh.n_tri, bvh.tri_pre);
+}

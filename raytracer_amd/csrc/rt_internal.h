@@ -1,0 +1,88 @@
+// rt_internal.h — shared declarations between the C-ABI layer (rt_api.hip) and the kernel
+// translation units (rt_build.hip, rt_trace.hip).  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/rtcore.h"
+
+// ---------------------------------------------------------------- device memory layout (HBM)
+// Interchange (public, web/script.js:526-561):
+//   nodes    f32[8N]   32 B/node  {mn.xyz, A | mx.xyz, B}
+//   tri_pos  f32[12T]  48 B/tri   3 x (x,y,z,0)
+//   tri_nor  f32[12T]  48 B/tri
+// Traversal layout (internal, derived by rt_pack_*):
+//   wide     float4[4*Ni] 64 B per internal node i:
+//              a = {c0.mn.xyz, bits(c0ref)}  b = {c0.mx.xyz, bits(c1ref)}
+//              c = {c1.mn.xyz, 0}            d = {c1.mx.xyz, 0}
+//            ref: bit31 clear = internal node index; bit31 set = leaf:
+//                 start = ref & ((1<<leaf_shift)-1), count = ((ref & 0x7fffffff) >> leaf_shift) + 1
+//   tri_pre  float4[3T]  48 B/tri: {v0.xyz, ng.x} {e1.xyz, ng.y} {e2.xyz, ng.z}
+//            e1 = v1-v0, e2 = v2-v0, ng = cross(e1,e2): the exact sub-expressions of
+//            triIntersect_fast / the back-face pre-cull (compute.wgsl:114-115,282), hoisted.
+struct RtBvhDev {
+  float*  nodes = nullptr;
+  float*  tri_pos = nullptr;
+  float*  tri_nor = nullptr;
+  float4* wide = nullptr;
+  float4* tri_pre = nullptr;
+  uint32_t n_nodes = 0, n_tri = 0, n_wide = 0;
+  uint32_t root_ref = 0;     // traversal ref of node 0
+  int      leaf_shift = 23;
+  bool     owns_interchange = true;
+};
+
+struct RtRenderParams {
+  const float*  nodes;
+  const float*  tri_pos;
+  const float*  tri_nor;
+  const float4* wide;
+  const float4* tri_pre;
+  uint32_t root_ref;
+  int      leaf_shift;
+  float    U[44];
+  int mode, gi_samples, gi_bounces, soft_samples, max_stack;
+  uint32_t width, height;
+  int stripe_rows, stripe_rank, stripe_world;   // stripe_rows == 0: whole image
+  uint32_t tiles_x, n_tiles, local_rows;
+  uint8_t*  rgba8;     // packed local rows
+  uint32_t* hit_tri;
+  float*    hit_t;
+  uint32_t* tile_counter;          // zeroed before launch
+  unsigned long long* stats;       // [8]: rays_primary, rays_shadow, rays_bounce, box, tri, hitupd, pixels, drops
+};
+
+// ---------------------------------------------------------------- build pipeline (rt_build.hip)
+struct RtBuildBuffers {
+  const float* pos; const float* nor; const uint32_t* vidx; const uint32_t* nidx;
+  uint32_t n_tri;
+  uint32_t* bounds_enc;     // [6] ordered-uint min.xyz / max.xyz
+  float*    bounds_f;       // [8] `Bounds` uniform: min.xyz,0, invExtent.xyz,0 (morton_compute.wgsl:3-6)
+  uint32_t* codes;          // [T] unsorted Morton codes
+  uint32_t* keys_a; uint32_t* keys_b;     // sort ping-pong
+  uint32_t* vals_a; uint32_t* vals_b;
+  uint32_t* hist;           // [4*256] global digit histograms -> exclusive bases
+  uint32_t* tile_status;    // [4][n_tiles][256] look-back words
+  uint32_t* tile_counter;   // [4]
+  uint32_t* err_flag;       // [1]
+  int32_t*  child;          // [2*(T-1)] child node ids
+  int32_t*  parent;         // [2T-1]
+  uint32_t* visit;          // [T-1] refit arrival counters
+  uint32_t  n_sort_tiles;
+};
+uint32_t rt_sort_tile_count(uint32_t n);
+size_t   rt_sort_status_words(uint32_t n);
+void rt_launch_bounds(const RtBuildBuffers& b, hipStream_t s);
+void rt_launch_morton(const RtBuildBuffers& b, hipStream_t s);
+void rt_launch_sort(const RtBuildBuffers& b, hipStream_t s);      // result in keys_a / vals_a
+void rt_launch_karras(const RtBuildBuffers& b, hipStream_t s);
+void rt_launch_refit(const RtBuildBuffers& b, float* nodes, float* tri_pos, float* tri_nor, hipStream_t s);
+// derive the traversal layout from the interchange buffers; writes the root ref / error bits
+void rt_launch_pack_impl(const RtBvhDev& bvh, uint32_t* d_root_ref, uint32_t* d_err, hipStream_t s);
+
+// ---------------------------------------------------------------- traversal (rt_trace.hip)
+void rt_launch_render(const RtRenderParams& p, int layout, bool count_work, int n_cu, hipStream_t s);
+void rt_launch_deinterleave(const void* packed, void* image, uint32_t width, uint32_t height, uint32_t elem_bytes,
+                            int stripe_rows, int world, uint32_t rows_per_rank, hipStream_t s);

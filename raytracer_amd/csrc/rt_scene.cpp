@@ -1,0 +1,441 @@
+// rt_scene.cpp — host-side scene input of librtcore: OBJ/MTL ingest, mesh normalisation and
+// the 176-byte uniform block.  Pure C++ (no HIP); usable without a GPU.
+//
+// Reference behaviour restated here:
+//   OBJ/MTL   tiny_obj_loader v2.0.0 (/root/reference/tiny_obj_loader.h): float grammar and
+//             arithmetic of tryParseDouble :954-1122, index fix-up :867-907, face triples
+//             :1312-1372, quad split along the shorter diagonal :1701-1813, material keys
+//             :188-247.  Polygons with more than 4 corners are fanned (tiny_obj_loader
+//             ear-clips them; neither fixture mesh has any).
+//   normalizeMesh  web/script.js:207-227
+//   uniforms       web/script.js:30-154, 591-612, 880-929 ; layout web/compute.wgsl:4-13
+#include "../../include/rtcore.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+struct rt_mesh {
+  std::vector<float> pos, nor, tex;
+  std::vector<uint32_t> vidx, nidx, tidx;
+  std::vector<int32_t> mat_ids;
+  std::vector<rt_material> materials;
+};
+
+namespace {
+
+inline bool is_digit(char c) { return c >= '0' && c <= '9'; }
+inline bool is_blank(char c) { return c == ' ' || c == '\t'; }
+
+// Number grammar and arithmetic of tiny_obj_loader.h:954-1122: digits are accumulated in
+// double (m = m*10 + d; fraction digits add d * 10^-k from a table for k < 8), a decimal
+// exponent E is applied as ldexp(m * 5^E, E).  Not correctly rounded — kept on purpose so
+// parsed floats equal what the reference's loader would produce.
+bool parse_number(const char* s, const char* end, double* out) {
+  if (s >= end) return false;
+  static const double frac_lut[8] = {1.0, 0.1, 0.01, 0.001, 0.0001, 0.00001, 0.000001, 0.0000001};
+  const char* c = s;
+  bool neg = false, dot_first = false;
+  if (*c == '+' || *c == '-') {
+    neg = (*c == '-');
+    ++c;
+    if (c != end && *c == '.') dot_first = true;
+  } else if (*c == '.') {
+    dot_first = true;
+  } else if (!is_digit(*c)) {
+    return false;
+  }
+  double m = 0.0;
+  int ndig = 0;
+  if (!dot_first) {
+    while (c != end && is_digit(*c)) { m *= 10; m += (int)(*c - '0'); ++c; ++ndig; }
+    if (ndig == 0) return false;
+  }
+  int exp10 = 0;
+  if (c != end && *c == '.') {
+    ++c;
+    int k = 1;
+    while (c != end && is_digit(*c)) {
+      m += (int)(*c - '0') * (k < 8 ? frac_lut[k] : std::pow(10.0, -k));
+      ++k; ++c;
+    }
+  } else if (c != end && (*c == 'e' || *c == 'E')) {
+    // handled below
+  } else {
+    *out = neg ? -m : m;
+    return true;
+  }
+  if (c != end && (*c == 'e' || *c == 'E')) {
+    ++c;
+    bool eneg = false;
+    if (c != end && (*c == '+' || *c == '-')) { eneg = (*c == '-'); ++c; }
+    else if (c == end || !is_digit(*c)) return false;
+    int nd = 0;
+    while (c != end && is_digit(*c)) {
+      if (exp10 > 2147483647 / 10) return false;
+      exp10 = exp10 * 10 + (int)(*c - '0');
+      ++c; ++nd;
+    }
+    if (nd == 0) return false;
+    if (eneg) exp10 = -exp10;
+  }
+  double v = exp10 ? std::ldexp(m * std::pow(5.0, exp10), exp10) : m;
+  *out = neg ? -v : v;
+  return true;
+}
+
+struct Cursor {
+  const char* p;
+  void skip_blank() { while (is_blank(*p)) ++p; }
+  const char* token_end() const { const char* e = p; while (*e && *e != ' ' && *e != '\t' && *e != '\r') ++e; return e; }
+  float real(double dflt = 0.0) {                 // parseReal, tiny_obj_loader.h:1124-1133
+    skip_blank();
+    const char* e = token_end();
+    double v = dflt;
+    parse_number(p, e, &v);
+    p = e;
+    return (float)v;
+  }
+  std::string word() { skip_blank(); const char* e = token_end(); std::string s(p, e); p = e; return s; }
+  std::string rest() {
+    skip_blank();
+    std::string s(p);
+    while (!s.empty() && (s.back() == '\r' || s.back() == '\n' || is_blank(s.back()))) s.pop_back();
+    return s;
+  }
+  bool at_end() { skip_blank(); return *p == 0 || *p == '\r' || *p == '\n'; }
+};
+
+struct Corner { int v, vt, vn; };
+
+// index fix-up, tiny_obj_loader.h:867-907: 1-based -> 0-based, negative = relative to count
+bool fix_index(int raw, int count, bool allow_zero, int* out) {
+  if (raw > 0) { *out = raw - 1; return true; }
+  if (raw == 0) { *out = -1; return allow_zero; }
+  *out = count + raw;
+  return *out >= 0;
+}
+inline void skip_to_sep(const char*& p) { while (*p && *p != '/' && *p != ' ' && *p != '\t' && *p != '\r') ++p; }
+
+// i, i/j, i//k, i/j/k — tiny_obj_loader.h:1312-1372
+bool parse_corner(const char*& p, int nv, int nvn, int nvt, Corner* c) {
+  c->v = c->vt = c->vn = -1;
+  if (!fix_index(atoi(p), nv, false, &c->v)) return false;
+  skip_to_sep(p);
+  if (*p != '/') return true;
+  ++p;
+  if (*p == '/') {
+    ++p;
+    if (!fix_index(atoi(p), nvn, true, &c->vn)) return false;
+    skip_to_sep(p);
+    return true;
+  }
+  if (!fix_index(atoi(p), nvt, true, &c->vt)) return false;
+  skip_to_sep(p);
+  if (*p != '/') return true;
+  ++p;
+  if (!fix_index(atoi(p), nvn, true, &c->vn)) return false;
+  skip_to_sep(p);
+  return true;
+}
+
+void parse_mtl(const std::string& text, std::vector<rt_material>& mats, std::map<std::string, int>& by_name) {
+  std::istringstream in(text);
+  std::string line;
+  rt_material cur;
+  bool have = false;
+  auto reset = [&](const std::string& name) {
+    std::memset(&cur, 0, sizeof(cur));
+    std::snprintf(cur.name, sizeof(cur.name), "%s", name.c_str());
+    cur.diffuse[0] = cur.diffuse[1] = cur.diffuse[2] = 0.6f;   // tinyobj InitMaterial leaves 0; Kd is normally present
+    cur.dissolve = 1.0f;
+    cur.illum = 0;
+  };
+  auto flush = [&]() { if (have) { by_name[cur.name] = (int)mats.size(); mats.push_back(cur); } };
+  while (std::getline(in, line)) {
+    Cursor c{line.c_str()};
+    c.skip_blank();
+    if (*c.p == 0 || *c.p == '#' || *c.p == '\r') continue;
+    std::string key = c.word();
+    if (key == "newmtl") { flush(); reset(c.rest()); have = true; }
+    else if (!have) continue;
+    else if (key == "Kd") { for (int i = 0; i < 3; ++i) cur.diffuse[i] = c.real(); }
+    else if (key == "Ke") { for (int i = 0; i < 3; ++i) cur.emission[i] = c.real(); }
+    else if (key == "d") { cur.dissolve = c.real(1.0); }
+    else if (key == "Tr") { cur.dissolve = 1.0f - c.real(0.0); }
+    else if (key == "illum") { cur.illum = atoi(c.word().c_str()); }
+    else if (key == "map_Kd") { std::snprintf(cur.diffuse_texname, sizeof(cur.diffuse_texname), "%s", c.rest().c_str()); }
+    else if (key == "map_Bump" || key == "map_bump" || key == "bump") {
+      std::snprintf(cur.bump_texname, sizeof(cur.bump_texname), "%s", c.rest().c_str());
+    }
+  }
+  flush();
+}
+
+void set_err(char* err, size_t n, const std::string& msg) { if (err && n) std::snprintf(err, n, "%s", msg.c_str()); }
+
+int parse_obj(const std::string& text, const std::string* mtl_text, const std::string& mtl_dir,
+              rt_mesh** out, char* err, size_t err_len) {
+  auto* m = new rt_mesh();
+  std::map<std::string, int> mat_by_name;
+  if (mtl_text) parse_mtl(*mtl_text, m->materials, mat_by_name);
+  std::vector<Corner> face;
+  int cur_mat = -1;
+  size_t line_no = 0;
+  bool any_vn = false, any_vt = false;
+  std::vector<Corner> corners;  // 3 per output triangle
+  const char* p = text.c_str();
+  const char* text_end = p + text.size();
+  std::string line;
+  while (p < text_end) {
+    const char* nl = (const char*)memchr(p, '\n', (size_t)(text_end - p));
+    const char* le = nl ? nl : text_end;
+    line.assign(p, le);
+    p = nl ? nl + 1 : text_end;
+    ++line_no;
+    Cursor c{line.c_str()};
+    c.skip_blank();
+    const char* t = c.p;
+    if (t[0] == 0 || t[0] == '#' || t[0] == '\r') continue;
+    if (t[0] == 'v' && is_blank(t[1])) {
+      c.p = t + 2;
+      float x = c.real(), y = c.real(), z = c.real();
+      m->pos.push_back(x); m->pos.push_back(y); m->pos.push_back(z);
+    } else if (t[0] == 'v' && t[1] == 'n' && is_blank(t[2])) {
+      c.p = t + 3;
+      float x = c.real(), y = c.real(), z = c.real();
+      m->nor.push_back(x); m->nor.push_back(y); m->nor.push_back(z);
+      any_vn = true;
+    } else if (t[0] == 'v' && t[1] == 't' && is_blank(t[2])) {
+      c.p = t + 3;
+      float u = c.real(), v = c.real();
+      m->tex.push_back(u); m->tex.push_back(v);
+      any_vt = true;
+    } else if (t[0] == 'f' && is_blank(t[1])) {
+      c.p = t + 2;
+      face.clear();
+      const int nv = (int)(m->pos.size() / 3), nvn = (int)(m->nor.size() / 3), nvt = (int)(m->tex.size() / 2);
+      while (!c.at_end()) {
+        Corner k;
+        if (!parse_corner(c.p, nv, nvn, nvt, &k)) {
+          set_err(err, err_len, "invalid face index at line " + std::to_string(line_no));
+          delete m; return RT_ERR_IO;
+        }
+        if (k.v >= nv || k.vn >= nvn || k.vt >= nvt) {
+          set_err(err, err_len, "face index out of range at line " + std::to_string(line_no));
+          delete m; return RT_ERR_IO;
+        }
+        face.push_back(k);
+      }
+      const size_t n = face.size();
+      if (n < 3) continue;  // degenerate face: skipped with a warning in tiny_obj_loader
+      auto emit = [&](int a, int b, int cc) {
+        corners.push_back(face[a]); corners.push_back(face[b]); corners.push_back(face[cc]);
+        m->mat_ids.push_back(cur_mat);
+      };
+      if (n == 3) emit(0, 1, 2);
+      else if (n == 4) {
+        // split along the shorter diagonal, f32 arithmetic (tiny_obj_loader.h:1756-1802)
+        const float* P = m->pos.data();
+        auto V = [&](int i, int k) { return P[3 * face[i].v + k]; };
+        float e02[3], e13[3];
+        for (int k = 0; k < 3; ++k) { e02[k] = V(2, k) - V(0, k); e13[k] = V(3, k) - V(1, k); }
+        float s02 = e02[0] * e02[0] + e02[1] * e02[1] + e02[2] * e02[2];
+        float s13 = e13[0] * e13[0] + e13[1] * e13[1] + e13[2] * e13[2];
+        if (s02 < s13) { emit(0, 1, 2); emit(0, 2, 3); }
+        else { emit(0, 1, 3); emit(1, 2, 3); }
+      } else {
+        for (size_t i = 1; i + 1 < n; ++i) emit(0, (int)i, (int)i + 1);
+      }
+    } else if (!strncmp(t, "usemtl", 6) && is_blank(t[6])) {
+      c.p = t + 7;
+      std::string name = c.rest();
+      auto it = mat_by_name.find(name);
+      cur_mat = (it == mat_by_name.end()) ? -1 : it->second;
+    } else if (!strncmp(t, "mtllib", 6) && is_blank(t[6])) {
+      if (!mtl_text && !mtl_dir.empty()) {
+        c.p = t + 7;
+        std::string fn = c.rest();
+        std::ifstream f(mtl_dir + "/" + fn, std::ios::binary);
+        if (f) {
+          std::stringstream ss; ss << f.rdbuf();
+          parse_mtl(ss.str(), m->materials, mat_by_name);
+        }  // a missing .mtl is a warning, not an error (tiny_obj_loader behaviour)
+      }
+    }
+    // g / o / s / anything else: no effect on the flattened triangle list
+  }
+  // dummy entries so that "no normal" / "no texcoord" corners still index valid memory
+  const uint32_t dummy_n = (uint32_t)(m->nor.size() / 3), dummy_t = (uint32_t)(m->tex.size() / 2);
+  m->nor.insert(m->nor.end(), {0.0f, 0.0f, 0.0f});
+  m->tex.insert(m->tex.end(), {0.0f, 0.0f});
+  (void)any_vn; (void)any_vt;
+  m->vidx.reserve(corners.size()); m->nidx.reserve(corners.size()); m->tidx.reserve(corners.size());
+  for (const Corner& k : corners) {
+    m->vidx.push_back((uint32_t)k.v);
+    m->nidx.push_back(k.vn < 0 ? dummy_n : (uint32_t)k.vn);
+    m->tidx.push_back(k.vt < 0 ? dummy_t : (uint32_t)k.vt);
+  }
+  *out = m;
+  return RT_OK;
+}
+
+}  // namespace
+
+extern "C" int rt_mesh_parse_obj(const char* obj_text, size_t obj_len, const char* mtl_text, size_t mtl_len,
+                                 rt_mesh** out, char* err, size_t err_len) {
+  if (!obj_text || !out) return RT_ERR_INVALID;
+  std::string obj(obj_text, obj_len), mtl;
+  if (mtl_text) mtl.assign(mtl_text, mtl_len);
+  return parse_obj(obj, mtl_text ? &mtl : nullptr, "", out, err, err_len);
+}
+
+extern "C" int rt_mesh_load_obj(const char* obj_path, const char* mtl_dir, rt_mesh** out, char* err, size_t err_len) {
+  if (!obj_path || !out) return RT_ERR_INVALID;
+  std::ifstream f(obj_path, std::ios::binary);
+  if (!f) { set_err(err, err_len, std::string("cannot open ") + obj_path); return RT_ERR_IO; }
+  std::stringstream ss; ss << f.rdbuf();
+  std::string dir;
+  if (mtl_dir) dir = mtl_dir;
+  else {
+    std::string pth(obj_path);
+    size_t k = pth.find_last_of('/');
+    dir = (k == std::string::npos) ? "." : pth.substr(0, k);
+  }
+  return parse_obj(ss.str(), nullptr, dir, out, err, err_len);
+}
+
+extern "C" int rt_mesh_view_get(const rt_mesh* m, rt_mesh_view* v) {
+  if (!m || !v) return RT_ERR_INVALID;
+  v->positions = m->pos.data(); v->n_vert = (uint32_t)(m->pos.size() / 3);
+  v->normals = m->nor.data(); v->n_nor = (uint32_t)(m->nor.size() / 3);
+  v->texcoords = m->tex.data(); v->n_tex = (uint32_t)(m->tex.size() / 2);
+  v->vert_idx = m->vidx.data(); v->nor_idx = m->nidx.data(); v->tex_idx = m->tidx.data();
+  v->material_ids = m->mat_ids.data();
+  v->n_tri = (uint32_t)(m->vidx.size() / 3);
+  v->n_materials = (uint32_t)m->materials.size();
+  return RT_OK;
+}
+extern "C" int rt_mesh_material(const rt_mesh* m, uint32_t i, rt_material* out) {
+  if (!m || !out || i >= m->materials.size()) return RT_ERR_INVALID;
+  *out = m->materials[i];
+  return RT_OK;
+}
+extern "C" void rt_mesh_free(rt_mesh* m) { delete m; }
+
+// web/script.js:207-227 — bbox over all vertices, centre, scale by 1/max-extent; JS numbers
+// are doubles, the Float32Array store rounds to f32.
+extern "C" int rt_normalize_mesh(float* p, uint32_t n_vert) {
+  if (!p) return RT_ERR_INVALID;
+  double lo[3], hi[3];
+  for (int k = 0; k < 3; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+  for (uint32_t i = 0; i < n_vert; ++i)
+    for (int k = 0; k < 3; ++k) {
+      const double v = p[3 * (size_t)i + k];
+      if (v < lo[k]) lo[k] = v;
+      if (v > hi[k]) hi[k] = v;
+    }
+  double mid[3], span = 0.0;
+  for (int k = 0; k < 3; ++k) { mid[k] = (lo[k] + hi[k]) * 0.5; span = std::fmax(span, hi[k] - lo[k]); }
+  if (n_vert == 0) return RT_OK;
+  span = std::fmax(std::fmax(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+  const double sc = 1 / span;
+  for (size_t i = 0; i < (size_t)n_vert * 3; ++i) p[i] = (float)((p[i] - mid[i % 3]) * sc);
+  return RT_OK;
+}
+
+// ------------------------------------------------------------------ uniforms
+namespace {
+struct M4 { float f[16]; };   // flat, as the Float32Array of script.js:57-74
+
+M4 trs_matrix(const double r[3], const double s[3], const double t[3]) {   // script.js:30-75
+  const double cx = std::cos(r[0]), sx = std::sin(r[0]);
+  const double cy = std::cos(r[1]), sy = std::sin(r[1]);
+  const double cz = std::cos(r[2]), sz = std::sin(r[2]);
+  const double rot[3][3] = {                         // ZYX order
+      {cz * cy, cz * sy * sx - sz * cx, cz * sy * cx + sz * sx},
+      {sz * cy, sz * sy * sx + cz * cx, sz * sy * cx - cz * sx},
+      {-sy, cy * sx, cy * cx}};
+  M4 m;
+  for (int row = 0; row < 3; ++row) {
+    for (int col = 0; col < 3; ++col) m.f[4 * row + col] = (float)(rot[row][col] * s[col]);
+    m.f[4 * row + 3] = 0.0f;
+  }
+  m.f[12] = (float)t[0]; m.f[13] = (float)t[1]; m.f[14] = (float)t[2]; m.f[15] = 1.0f;
+  return m;
+}
+
+M4 inverse(const M4& in) {                            // script.js:77-133 (cofactor expansion in double)
+  double a[4][4];
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) a[i][j] = in.f[4 * i + j];
+  const double b00 = a[0][0] * a[1][1] - a[0][1] * a[1][0], b01 = a[0][0] * a[1][2] - a[0][2] * a[1][0];
+  const double b02 = a[0][0] * a[1][3] - a[0][3] * a[1][0], b03 = a[0][1] * a[1][2] - a[0][2] * a[1][1];
+  const double b04 = a[0][1] * a[1][3] - a[0][3] * a[1][1], b05 = a[0][2] * a[1][3] - a[0][3] * a[1][2];
+  const double b06 = a[2][0] * a[3][1] - a[2][1] * a[3][0], b07 = a[2][0] * a[3][2] - a[2][2] * a[3][0];
+  const double b08 = a[2][0] * a[3][3] - a[2][3] * a[3][0], b09 = a[2][1] * a[3][2] - a[2][2] * a[3][1];
+  const double b10 = a[2][1] * a[3][3] - a[2][3] * a[3][1], b11 = a[2][2] * a[3][3] - a[2][3] * a[3][2];
+  double det = b00 * b11 - b01 * b10 + b02 * b09 + b03 * b08 - b04 * b07 + b05 * b06;
+  M4 o;
+  for (float& v : o.f) v = 0.0f;                     // `new Float32Array(16)` stays zero when !det
+  if (!(det != 0.0)) return o;
+  det = 1.0 / det;
+  const double r[16] = {
+      (a[1][1] * b11 - a[1][2] * b10 + a[1][3] * b09) * det,  (-a[0][1] * b11 + a[0][2] * b10 - a[0][3] * b09) * det,
+      (a[3][1] * b05 - a[3][2] * b04 + a[3][3] * b03) * det,  (-a[2][1] * b05 + a[2][2] * b04 - a[2][3] * b03) * det,
+      (-a[1][0] * b11 + a[1][2] * b08 - a[1][3] * b07) * det, (a[0][0] * b11 - a[0][2] * b08 + a[0][3] * b07) * det,
+      (-a[3][0] * b05 + a[3][2] * b02 - a[3][3] * b01) * det, (a[2][0] * b05 - a[2][2] * b02 + a[2][3] * b01) * det,
+      (a[1][0] * b10 - a[1][1] * b08 + a[1][3] * b06) * det,  (-a[0][0] * b10 + a[0][1] * b08 - a[0][3] * b06) * det,
+      (a[3][0] * b04 - a[3][1] * b02 + a[3][3] * b00) * det,  (-a[2][0] * b04 + a[2][1] * b02 - a[2][3] * b00) * det,
+      (-a[1][0] * b09 + a[1][1] * b07 - a[1][2] * b06) * det, (a[0][0] * b09 - a[0][1] * b07 + a[0][2] * b06) * det,
+      (-a[3][0] * b03 + a[3][1] * b01 - a[3][2] * b00) * det, (a[2][0] * b03 - a[2][1] * b01 + a[2][2] * b00) * det};
+  for (int i = 0; i < 16; ++i) o.f[i] = (float)r[i];
+  return o;
+}
+
+struct D3 { double x, y, z; };
+D3 unit(D3 v) {                                      // script.js:678-681
+  double l = std::hypot(v.x, v.y, v.z);
+  if (!(l != 0.0)) l = 1.0;
+  return D3{v.x / l, v.y / l, v.z / l};
+}
+D3 crossd(D3 a, D3 b) { return D3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+}  // namespace
+
+extern "C" void rt_camera_default(rt_camera* cam, uint32_t width, uint32_t height) {
+  if (!cam) return;
+  std::memset(cam, 0, sizeof(*cam));
+  cam->pos[2] = 5.0;                                  // script.js:4
+  for (int i = 0; i < 3; ++i) cam->scale[i] = 1.0;   // web/index.html:12-22 slider defaults
+  cam->width = width; cam->height = height;
+}
+
+extern "C" int rt_make_uniforms(const rt_camera* cam, float u[44]) {
+  if (!cam || !u || cam->width == 0 || cam->height == 0) return RT_ERR_INVALID;
+  const double pi = 3.141592653589793;               // Math.PI
+  const double cp = std::cos(cam->pitch), sp = std::sin(cam->pitch);
+  const double cy = std::cos(cam->yaw), sy = std::sin(cam->yaw);
+  const D3 look{cp * sy, sp, -cp * cy};              // script.js:596
+  const D3 eye{cam->pos[0], cam->pos[1], cam->pos[2]};
+  const D3 tgt{eye.x + look.x, eye.y + look.y, eye.z + look.z};
+  const D3 fwd = unit(D3{tgt.x - eye.x, tgt.y - eye.y, tgt.z - eye.z});
+  const D3 right = unit(crossd(fwd, D3{0, 1, 0}));
+  const D3 up = crossd(right, fwd);
+  const double fov = pi / 3, aspect = (double)cam->width / (double)cam->height, fl = 1 / std::tan(fov / 2);
+  const double rot[3] = {(cam->rot_deg[0] * pi) / 180 - pi, (cam->rot_deg[1] * pi) / 180, (cam->rot_deg[2] * pi) / 180};
+  const M4 inv = inverse(trs_matrix(rot, cam->scale, cam->translate));
+  for (int i = 0; i < 44; ++i) u[i] = 0.0f;
+  u[0] = (float)eye.x; u[1] = (float)eye.y; u[2] = (float)eye.z;
+  u[4] = 5.0f; u[5] = -5.0f; u[6] = 5.0f; u[7] = 0.3f;                 // script.js:904-907
+  u[8] = (float)(right.x * fl * aspect); u[9] = (float)(right.y * fl * aspect); u[10] = (float)(right.z * fl * aspect);
+  u[12] = (float)(up.x * fl); u[13] = (float)(up.y * fl); u[14] = (float)(up.z * fl);
+  u[16] = (float)(fwd.x * fl); u[17] = (float)(fwd.y * fl); u[18] = (float)(fwd.z * fl);
+  for (int i = 0; i < 16; ++i) u[20 + i] = inv.f[i];
+  u[36] = (float)cam->width; u[37] = (float)cam->height;
+  u[38] = cam->time;
+  return RT_OK;
+}

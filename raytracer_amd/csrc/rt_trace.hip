@@ -1,0 +1,489 @@
+// rt_trace.hip — hot path 2: per-pixel ray/scene loop of web/compute.wgsl as a persistent-
+// thread, wave64 traversal kernel for gfx950.
+//
+// One lane = one pixel of an 8x8 tile; each wave pulls tiles from a global atomic counter
+// until the frame (or this rank's stripes) is drained.  The traversal stack lives in LDS
+// ([entry][thread], conflict-free) so that dynamic indexing never spills to scratch.
+//
+// Two node layouts (A/B, same results bit for bit):
+//   WIDE64 (default)  64-byte records holding BOTH children's boxes + refs, triangles with
+//                     hoisted edges: one 64 B fetch per internal step instead of the
+//                     reference's 3 x 32 B (compute.wgsl:273,303-304), stack entries carry the
+//                     child's entry distance so a pop needs no re-fetch.
+//   AOS32             literal walk over the 32-byte interchange records (compute.wgsl:259-346).
+// Semantics kept exactly: test order, near-child rule `b0.x <= b1.x`, the MAX_STACK-1 push
+// guard that silently drops the far child (F9), strict `<` closest-hit update, front-face
+// only Möller–Trumbore, child0-chain shadow walk (F8), shared RNG sequence (F7).
+#include "rt_device.h"
+#include "rt_internal.h"
+
+namespace {
+
+constexpr int TBLK = 256;
+constexpr uint32_t REF_DONE = 0xFFFFFFFFu;
+constexpr float TWO_PI_F = 6.283185307179586f;
+
+struct Work { uint32_t box, tri, hit, drops; };
+struct Hit { float t; uint32_t tri; float u, v; };
+
+struct Scene {
+  const float4* nodes;     // interchange records, 2 x float4 per node
+  const float4* tri_pos;   // 3 x float4 per triangle
+  const float4* tri_nor;
+  const float4* wide;
+  const float4* tri_pre;
+  uint32_t root_ref;
+  int leaf_shift;
+  int max_stack;
+  uint32_t* stk_ref;       // this thread's LDS column, stride TBLK
+  float*    stk_t;
+};
+
+// web/compute.wgsl:91-104
+RT_DEV void slab(V3 ro, V3 inv, V3 mn, V3 mx, float& tmin, float& tmax) {
+  const V3 t0 = (mn - ro) * inv, t1 = (mx - ro) * inv;
+  tmin = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fminf(t0.z, t1.z));
+  tmax = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fmaxf(t0.z, t1.z));
+}
+RT_DEV bool box_hit(float tmin, float tmax, float limit) { return (tmax >= fmaxf(tmin, 0.0f)) && (tmin <= limit); }
+
+// web/compute.wgsl:107-132 with e1/e2 supplied
+RT_DEV bool moller_trumbore(V3 ro, V3 rd, V3 v0, V3 e1, V3 e2, float& t, float& u, float& v) {
+  const V3 p = cross3(rd, e2);
+  const float det = dot3(e1, p);
+  const V3 s = ro - v0;
+  const float invDet = 1.0f / det;
+  u = dot3(s, p) * invDet;
+  const V3 q = cross3(s, e1);
+  v = dot3(rd, q) * invDet;
+  t = dot3(e2, q) * invDet;
+  return (det > 1e-10f) & (u >= 0.0f) & (v >= 0.0f) & ((u + v) <= 1.0f) & (t > 1e-10f);
+}
+
+// ---------------------------------------------------------------- WIDE64 traversal
+template <bool COUNT>
+RT_DEV Hit closest_wide(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Work& W) {
+  float bestT = maxDist, bu = 0.0f, bv = 0.0f;
+  uint32_t bestTri = 0xFFFFFFFFu;
+  int sp = 0;
+  uint32_t cur;
+  {
+    const float4 a = S.nodes[0], b = S.nodes[1];
+    float tn, tf; slab(ro, inv, xyz(a), xyz(b), tn, tf);
+    if (COUNT) W.box += 1;
+    cur = box_hit(tn, tf, bestT) ? S.root_ref : REF_DONE;
+  }
+  auto pop = [&]() -> uint32_t {
+    while (sp > 0) {
+      sp -= 1;
+      const float tn = S.stk_t[sp * TBLK];
+      if (tn <= bestT) return S.stk_ref[sp * TBLK];   // re-test of compute.wgsl:275 with the stored entry distance
+    }
+    return REF_DONE;
+  };
+  while (cur != REF_DONE) {
+    while ((int)cur >= 0) {                            // internal: both children from one 64 B record
+      const float4* n = S.wide + 4 * (size_t)cur;
+      const float4 a = n[0], b = n[1], c = n[2], d = n[3];
+      float t0n, t0f, t1n, t1f;
+      slab(ro, inv, xyz(a), xyz(b), t0n, t0f);
+      slab(ro, inv, xyz(c), xyz(d), t1n, t1f);
+      if (COUNT) W.box += 2;
+      const bool hit0 = box_hit(t0n, t0f, bestT), hit1 = box_hit(t1n, t1f, bestT);
+      const uint32_t r0 = __float_as_uint(a.w), r1 = __float_as_uint(b.w);
+      if (hit0 && hit1) {
+        const bool first0 = (t0n <= t1n);              // compute.wgsl:310
+        if (sp < S.max_stack - 1) {                    // :311 / :317 — otherwise the far child is dropped
+          S.stk_ref[sp * TBLK] = first0 ? r1 : r0;
+          S.stk_t[sp * TBLK] = first0 ? t1n : t0n;
+          sp += 1;
+        } else if (COUNT) W.drops += 1;
+        cur = first0 ? r0 : r1;
+      } else if (hit0) cur = r0;
+      else if (hit1) cur = r1;
+      else cur = pop();
+    }
+    if (cur == REF_DONE) break;
+    const uint32_t body = cur & 0x7FFFFFFFu;
+    const uint32_t start = (S.leaf_shift >= 31) ? body : (body & ((1u << S.leaf_shift) - 1u));
+    const uint32_t count = (S.leaf_shift >= 31) ? 1u : ((body >> S.leaf_shift) + 1u);
+    for (uint32_t j = 0; j < count; ++j) {
+      const uint32_t ti = start + j;
+      const float4 q0 = S.tri_pre[3 * (size_t)ti + 0], q1 = S.tri_pre[3 * (size_t)ti + 1], q2 = S.tri_pre[3 * (size_t)ti + 2];
+      if (COUNT) W.tri += 1;
+      if (dot3(v3(q0.w, q1.w, q2.w), rd) > 0.0f) continue;        // back-face pre-cull, compute.wgsl:282
+      float t, u, v;
+      const bool hit = moller_trumbore(ro, rd, xyz(q0), xyz(q1), xyz(q2), t, u, v);
+      if (hit && t < bestT) { bestT = t; bestTri = ti; bu = u; bv = v; if (COUNT) W.hit += 1; }
+    }
+    cur = pop();
+  }
+  Hit h; h.t = bestT; h.tri = bestTri; h.u = bu; h.v = bv;
+  return h;
+}
+
+template <bool COUNT>
+RT_DEV bool occluded_wide(const Scene& S, V3 ro, V3 rd, float maxDist, Work& W) {
+  const V3 inv = rcp3(rd);
+  {
+    const float4 a = S.nodes[0], b = S.nodes[1];
+    float tn, tf; slab(ro, inv, xyz(a), xyz(b), tn, tf);
+    if (COUNT) W.box += 1;
+    if (!box_hit(tn, tf, maxDist)) return false;
+  }
+  uint32_t cur = S.root_ref;
+  while ((int)cur >= 0) {                              // child0 chain only (compute.wgsl:187)
+    const float4* n = S.wide + 4 * (size_t)cur;
+    const float4 a = n[0], b = n[1];
+    float tn, tf; slab(ro, inv, xyz(a), xyz(b), tn, tf);
+    if (COUNT) W.box += 1;
+    if (!box_hit(tn, tf, maxDist)) return false;
+    cur = __float_as_uint(a.w);
+  }
+  const uint32_t body = cur & 0x7FFFFFFFu;
+  const uint32_t start = (S.leaf_shift >= 31) ? body : (body & ((1u << S.leaf_shift) - 1u));
+  const uint32_t count = (S.leaf_shift >= 31) ? 1u : ((body >> S.leaf_shift) + 1u);
+  for (uint32_t j = 0; j < count; ++j) {
+    const uint32_t ti = start + j;
+    const float4 q0 = S.tri_pre[3 * (size_t)ti + 0], q1 = S.tri_pre[3 * (size_t)ti + 1], q2 = S.tri_pre[3 * (size_t)ti + 2];
+    if (COUNT) W.tri += 1;
+    float t, u, v;
+    if (moller_trumbore(ro, rd, xyz(q0), xyz(q1), xyz(q2), t, u, v) && t < maxDist) return true;
+  }
+  return false;
+}
+
+// ---------------------------------------------------------------- AOS32 traversal (literal)
+struct NodeRec { V3 mn, mx; int c0, c1; bool leaf; int start, count; };
+RT_DEV NodeRec fetch_node(const Scene& S, int idx) {   // compute.wgsl:68-88
+  const float4 a = S.nodes[2 * (size_t)(uint32_t)idx], b = S.nodes[2 * (size_t)(uint32_t)idx + 1];
+  NodeRec n;
+  n.mn = xyz(a); n.mx = xyz(b);
+  n.leaf = (b.w < 0.0f);
+  if (n.leaf) { n.start = sat_i32(a.w); n.count = -sat_i32(b.w); n.c0 = -1; n.c1 = -1; }
+  else { n.c0 = sat_i32(a.w); n.c1 = sat_i32(b.w); n.start = -1; n.count = 0; }
+  return n;
+}
+
+template <bool COUNT>
+RT_DEV Hit closest_aos(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Work& W) {
+  float bestT = maxDist, bu = 0.0f, bv = 0.0f;
+  uint32_t bestTri = 0xFFFFFFFFu;
+  int sp = 0, cur = 0;
+  if (COUNT) W.box += 1;
+  for (;;) {
+    if (cur < 0 || sp >= S.max_stack) break;
+    const NodeRec node = fetch_node(S, cur);
+    float hx, hy; slab(ro, inv, node.mn, node.mx, hx, hy);
+    bool go_pop = false;
+    if (box_hit(hx, hy, bestT)) {
+      if (node.leaf) {
+        for (int j = 0; j < node.count; ++j) {
+          const uint32_t ti = (uint32_t)(node.start + j);
+          const V3 va = xyz(S.tri_pos[3 * (size_t)ti + 0]), vb = xyz(S.tri_pos[3 * (size_t)ti + 1]), vc = xyz(S.tri_pos[3 * (size_t)ti + 2]);
+          if (COUNT) W.tri += 1;
+          const V3 e1 = vb - va, e2 = vc - va;
+          if (dot3(cross3(e1, e2), rd) > 0.0f) continue;
+          float t, u, v;
+          const bool hit = moller_trumbore(ro, rd, va, e1, e2, t, u, v);
+          if (hit && t < bestT) { bestT = t; bestTri = ti; bu = u; bv = v; if (COUNT) W.hit += 1; }
+        }
+        go_pop = true;
+      } else {
+        const NodeRec n0 = fetch_node(S, node.c0), n1 = fetch_node(S, node.c1);
+        float b0x, b0y, b1x, b1y;
+        slab(ro, inv, n0.mn, n0.mx, b0x, b0y);
+        slab(ro, inv, n1.mn, n1.mx, b1x, b1y);
+        if (COUNT) W.box += 2;
+        const bool hit0 = box_hit(b0x, b0y, bestT), hit1 = box_hit(b1x, b1y, bestT);
+        if (hit0 && hit1) {
+          const bool first0 = (b0x <= b1x);
+          if (sp < S.max_stack - 1) { S.stk_ref[sp * TBLK] = (uint32_t)(first0 ? node.c1 : node.c0); sp += 1; }
+          else if (COUNT) W.drops += 1;
+          cur = first0 ? node.c0 : node.c1;
+        } else if (hit0) cur = node.c0;
+        else if (hit1) cur = node.c1;
+        else go_pop = true;
+      }
+    } else go_pop = true;
+    if (go_pop) {
+      if (sp > 0) { sp -= 1; cur = (int)S.stk_ref[sp * TBLK]; } else break;
+    }
+  }
+  Hit h; h.t = bestT; h.tri = bestTri; h.u = bu; h.v = bv;
+  return h;
+}
+
+template <bool COUNT>
+RT_DEV bool occluded_aos(const Scene& S, V3 ro, V3 rd, float maxDist, Work& W) {   // compute.wgsl:166-194
+  const V3 inv = rcp3(rd);
+  int cur = 0;
+  for (;;) {
+    if (cur < 0) break;
+    const NodeRec node = fetch_node(S, cur);
+    float hx, hy; slab(ro, inv, node.mn, node.mx, hx, hy);
+    if (COUNT) W.box += 1;
+    if (!box_hit(hx, hy, maxDist)) break;
+    if (node.leaf) {
+      for (int j = 0; j < node.count; ++j) {
+        const uint32_t ti = (uint32_t)(node.start + j);
+        const V3 va = xyz(S.tri_pos[3 * (size_t)ti + 0]), vb = xyz(S.tri_pos[3 * (size_t)ti + 1]), vc = xyz(S.tri_pos[3 * (size_t)ti + 2]);
+        if (COUNT) W.tri += 1;
+        float t, u, v;
+        if (moller_trumbore(ro, rd, va, vb - va, vc - va, t, u, v) && t < maxDist) return true;
+      }
+      break;
+    }
+    cur = node.c0;
+  }
+  return false;
+}
+
+template <int LAYOUT, bool COUNT>
+RT_DEV Hit closest(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Work& W) {
+  if constexpr (LAYOUT == RT_LAYOUT_WIDE64) return closest_wide<COUNT>(S, ro, rd, inv, maxDist, W);
+  else return closest_aos<COUNT>(S, ro, rd, inv, maxDist, W);
+}
+template <int LAYOUT, bool COUNT>
+RT_DEV bool occluded(const Scene& S, V3 ro, V3 rd, float maxDist, Work& W) {
+  if constexpr (LAYOUT == RT_LAYOUT_WIDE64) return occluded_wide<COUNT>(S, ro, rd, maxDist, W);
+  else return occluded_aos<COUNT>(S, ro, rd, maxDist, W);
+}
+
+// interpolated shading normal of the winning triangle (compute.wgsl:288-291), evaluated once
+RT_DEV V3 hit_normal(const Scene& S, const Hit& h) {
+  const V3 n0 = xyz(S.tri_nor[3 * (size_t)h.tri + 0]), n1 = xyz(S.tri_nor[3 * (size_t)h.tri + 1]), n2 = xyz(S.tri_nor[3 * (size_t)h.tri + 2]);
+  return normalize3(fma3(n2, h.v, fma3(n1, h.u, n0 * ((1.0f - h.u) - h.v))));
+}
+
+// ---------------------------------------------------------------- shading
+struct Shade { int mode, gi_samples, gi_bounces, soft_samples; };
+struct RayCount { uint32_t primary, shadow, bounce; };
+
+// web/compute.wgsl:153-163
+RT_DEV V3 sample_hemisphere(V3 n, float s1, float s2) {
+  const float theta = TWO_PI_F * s1;
+  const float r = sqrtf(s2);
+  float sn, cs; rt_sincos(theta, &sn, &cs);
+  const float x = r * cs, y = r * sn;
+  const float z = sqrtf(fmaxf(0.0f, 1.0f - s2));
+  const V3 up = (fabsf(n.y) < 0.999f) ? v3(0.0f, 1.0f, 0.0f) : v3(1.0f, 0.0f, 0.0f);
+  const V3 T = normalize3(cross3(up, n));
+  const V3 B = cross3(n, T);
+  return normalize3((T * x + B * y) + n * z);
+}
+
+// web/compute.wgsl:197-256
+template <int LAYOUT, bool COUNT>
+RT_DEV float direct_radiance(const Scene& S, const Shade& sh, V3 hit_os, V3 n_os, V3 light_os, uint32_t seed_id,
+                             float time_h, Work& W, RayCount& R) {
+  const V3 hitToLight = light_os - hit_os;
+  const V3 L = normalize3(hitToLight);
+  const float diff = fmaxf(dot3(n_os, L), 0.0f);
+  if (diff <= 0.0f) return 0.0f;
+  if (sh.mode == RT_MODE_PRIMARY) return diff;
+  uint32_t occ = 0;
+  const V3 up = (fabsf(n_os.y) > 0.99f) ? v3(1.0f, 0.0f, 0.0f) : v3(0.0f, 1.0f, 0.0f);
+  const V3 tangent = normalize3(cross3(up, n_os));
+  const V3 bitangent = cross3(n_os, tangent);
+  const V3 ro2 = fma3(n_os, 0.001f, hit_os);
+  const float lightDist = length3(hitToLight);
+  const uint32_t GI = (uint32_t)sh.gi_samples, SOFT = (uint32_t)sh.soft_samples;
+  const float sqrtS = ceilf(sqrtf((float)GI));
+  const uint32_t cols = sat_u32(sqrtS);
+  const uint32_t rows = (GI + cols - 1u) / cols;
+  for (uint32_t i = 0; i < SOFT; ++i) {
+    const uint32_t sx = i % cols, sy = i / cols;
+    const float jitter1 = rand2((float)(seed_id + 17u) + time_h, (float)i + 0.37f);
+    const float jitter2 = rand2((float)(seed_id + 91u) + time_h, (float)i + 1.13f);
+    const float s1 = ((float)sx + jitter1) / (float)cols;
+    const float s2 = ((float)sy + jitter2) / (float)rows;
+    const float theta = TWO_PI_F * s1;
+    const float r = sqrtf(s2);
+    float sn, cs; rt_sincos(theta, &sn, &cs);
+    const float x = r * cs, y = r * sn;
+    const float z = sqrtf(fmaxf(0.0f, 1.0f - s2));
+    const V3 rd2 = normalize3((tangent * x + bitangent * y) + n_os * z);
+    const bool visible = dot3(rd2, L) > 0.5f;
+    R.shadow += 1;
+    const bool hit = occluded<LAYOUT, COUNT>(S, ro2, rd2, lightDist - 0.001f, W);
+    occ += (visible & hit) ? 1u : 0u;
+  }
+  const float shadowFactor = __fmaf_rn(-(float)occ, 1.0f / (float)SOFT, 1.0f);
+  return diff * shadowFactor;
+}
+
+RT_DEV V3 mat_mul4(const float* m, float x, float y, float z, float w) {
+  return v3(((m[0] * x + m[4] * y) + m[8] * z) + m[12] * w, ((m[1] * x + m[5] * y) + m[9] * z) + m[13] * w,
+            ((m[2] * x + m[6] * y) + m[10] * z) + m[14] * w);
+}
+RT_DEV V3 mat_mul3(const float* m, V3 v) {
+  return v3((m[0] * v.x + m[4] * v.y) + m[8] * v.z, (m[1] * v.x + m[5] * v.y) + m[9] * v.z, (m[2] * v.x + m[6] * v.y) + m[10] * v.z);
+}
+RT_DEV uint32_t unorm8(float c) { return sat_u32(floorf(fminf(fmaxf(c, 0.0f), 1.0f) * 255.0f + 0.5f)); }
+
+struct PixelOut { uint32_t rgba; uint32_t tri; float t; };
+
+// web/compute.wgsl:349-410 + :419-444
+template <int LAYOUT, bool COUNT>
+RT_DEV PixelOut shade_pixel(const Scene& S, const Shade& sh, const float* U, uint32_t gx, uint32_t gy, uint32_t w, uint32_t h,
+                            float time_h, Work& W, RayCount& R) {
+  const float uvx = ((float)gx + 0.5f) / (float)w, uvy = ((float)gy + 0.5f) / (float)h;
+  const V3 ro_w = v3(U[0], U[1], U[2]);
+  const float sx = __fmaf_rn(uvx, 2.0f, -1.0f), sy = __fmaf_rn(uvy, 2.0f, -1.0f);
+  const V3 rd_w = normalize3(fma3(v3(U[8], U[9], U[10]), sx, fma3(v3(U[12], U[13], U[14]), sy, v3(U[16], U[17], U[18]))));
+  const float px = fminf(fmaxf(uvx * (float)w, 0.0f), (float)(w - 1));
+  const float py = fminf(fmaxf(uvy * (float)h, 0.0f), (float)(h - 1));
+  const uint32_t pixelIndex = sat_u32(py) * w + sat_u32(px);
+
+  const float* model = U + 20;
+  const V3 ro_os = mat_mul4(model, ro_w.x, ro_w.y, ro_w.z, 1.0f);
+  const V3 rd_os = normalize3(mat_mul3(model, rd_w));
+  const V3 invRd = rcp3(rd_os);
+  const V3 light_os = mat_mul4(model, U[4], U[5], U[6], U[7]);
+
+  PixelOut out;
+  R.primary += 1;
+  const Hit hit0 = closest<LAYOUT, COUNT>(S, ro_os, rd_os, invRd, 1e20f, W);
+  out.tri = hit0.tri; out.t = hit0.t;
+  if (hit0.t >= 1e19f) { out.rgba = 0xFF000000u; out.tri = 0xFFFFFFFFu; return out; }   // (0,0,0,1)
+
+  const V3 hit_pos = fma3(rd_os, hit0.t, ro_os);
+  const V3 n_os = hit_normal(S, hit0);
+  const V3 albedo = v3(1.0f, 0.84f, 0.0f);
+  V3 indirect = v3(0.0f, 0.0f, 0.0f);
+  if (sh.mode == RT_MODE_PT) {
+    const uint32_t GI = (uint32_t)sh.gi_samples, NB = (uint32_t)sh.gi_bounces;
+    const float pixelSeed = (float)pixelIndex / (U[36] * U[37]);
+    for (uint32_t i = 0; i < GI; ++i) {
+      V3 throughput = albedo;
+      V3 ro_b = fma3(n_os, 0.001f, hit_pos);
+      V3 n_b = n_os;
+      for (uint32_t b = 0; b < NB; ++b) {
+        const float bounceSeed = (float)b * 101.0f + (float)i;
+        const float s1 = rand2(bounceSeed, __fmaf_rn(pixelSeed, (float)i, 17.0f) + time_h);
+        const float s2 = rand2(__fmaf_rn(pixelSeed, (float)i, 37.0f) + time_h, bounceSeed);
+        const V3 dir = sample_hemisphere(n_b, s1, s2);
+        R.bounce += 1;
+        const Hit hb = closest<LAYOUT, COUNT>(S, ro_b, dir, rcp3(dir), 1e20f, W);
+        if (hb.t >= 1e19f) break;
+        const V3 pB = fma3(dir, hb.t, ro_b);
+        const V3 nB = hit_normal(S, hb);
+        const float dS = direct_radiance<LAYOUT, COUNT>(S, sh, pB, nB, light_os, pixelIndex, time_h, W, R);
+        indirect = indirect + throughput * dS;
+        throughput = throughput * albedo;
+        ro_b = fma3(nB, 0.0001f, pB);
+        n_b = nB;
+      }
+    }
+    indirect = indirect / (float)GI;
+  }
+  const float d0 = direct_radiance<LAYOUT, COUNT>(S, sh, hit_pos, n_os, light_os, pixelIndex, time_h, W, R);
+  const V3 col = v3(__fmaf_rn(albedo.x, d0, indirect.x), __fmaf_rn(albedo.y, d0, indirect.y), __fmaf_rn(albedo.z, d0, indirect.z));
+  const float g = 1.0f / 2.2f;
+  out.rgba = unorm8(rt_pow(col.x, g)) | (unorm8(rt_pow(col.y, g)) << 8) | (unorm8(rt_pow(col.z, g)) << 16) | 0xFF000000u;
+  return out;
+}
+
+RT_DEV uint32_t wave_sum_u32(uint32_t v) {
+  for (int o = 32; o >= 1; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
+  return v;
+}
+
+template <int LAYOUT, bool COUNT>
+__global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  uint32_t* stk_ref = reinterpret_cast<uint32_t*>(smem);
+  float* stk_t = reinterpret_cast<float*>(smem + sizeof(uint32_t) * (size_t)p.max_stack * TBLK);
+
+  Scene S;
+  S.nodes = reinterpret_cast<const float4*>(p.nodes);
+  S.tri_pos = reinterpret_cast<const float4*>(p.tri_pos);
+  S.tri_nor = reinterpret_cast<const float4*>(p.tri_nor);
+  S.wide = p.wide; S.tri_pre = p.tri_pre;
+  S.root_ref = p.root_ref; S.leaf_shift = p.leaf_shift; S.max_stack = p.max_stack;
+  S.stk_ref = stk_ref + threadIdx.x; S.stk_t = stk_t + threadIdx.x;
+  Shade sh; sh.mode = p.mode; sh.gi_samples = p.gi_samples; sh.gi_bounces = p.gi_bounces; sh.soft_samples = p.soft_samples;
+
+  const int lane = threadIdx.x & 63;
+  const float time_h = (float)hash_u32(sat_u32(p.U[38]));          // compute.wgsl:444
+  Work W; W.box = W.tri = W.hit = W.drops = 0;
+  RayCount R; R.primary = R.shadow = R.bounce = 0;
+  uint32_t pixels = 0;
+
+  for (;;) {                                             // persistent: every wave drains the tile queue
+    uint32_t tile = 0;
+    if (lane == 0) tile = atomicAdd(p.tile_counter, 1u);
+    tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
+    if (tile >= p.n_tiles) break;
+    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const uint32_t x = tx * 8u + (uint32_t)(lane & 7), lrow = ty * 8u + (uint32_t)(lane >> 3);
+    uint32_t y = lrow;
+    if (p.stripe_rows > 0) {
+      const uint32_t sl = lrow / (uint32_t)p.stripe_rows, rin = lrow % (uint32_t)p.stripe_rows;
+      y = (sl * (uint32_t)p.stripe_world + (uint32_t)p.stripe_rank) * (uint32_t)p.stripe_rows + rin;
+    }
+    if (x < p.width && lrow < p.local_rows && y < p.height) {
+      const PixelOut o = shade_pixel<LAYOUT, COUNT>(S, sh, p.U, x, y, p.width, p.height, time_h, W, R);
+      const size_t idx = (size_t)lrow * p.width + x;
+      if (p.rgba8) reinterpret_cast<uint32_t*>(p.rgba8)[idx] = o.rgba;
+      if (p.hit_tri) p.hit_tri[idx] = o.tri;
+      if (p.hit_t) p.hit_t[idx] = o.t;
+      pixels += 1;
+    }
+  }
+  // one atomic per wave and counter
+  uint32_t c[8] = {R.primary, R.shadow, R.bounce, W.box, W.tri, W.hit, pixels, W.drops};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (!COUNT && (k == 3 || k == 4 || k == 5 || k == 7)) continue;
+    const uint32_t s = wave_sum_u32(c[k]);
+    if (lane == 0 && s) atomicAdd(&p.stats[k], (unsigned long long)s);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(TBLK) void k_deinterleave(const T* __restrict__ packed, T* __restrict__ image, uint32_t width,
+                                                       uint32_t height, int stripe_rows, int world, uint32_t rows_per_rank) {
+  const size_t n = (size_t)width * height;
+  for (size_t i = (size_t)blockIdx.x * TBLK + threadIdx.x; i < n; i += (size_t)gridDim.x * TBLK) {
+    const uint32_t y = (uint32_t)(i / width), x = (uint32_t)(i % width);
+    const uint32_t stripe = y / (uint32_t)stripe_rows, rin = y % (uint32_t)stripe_rows;
+    const uint32_t rank = stripe % (uint32_t)world, sl = stripe / (uint32_t)world;
+    const size_t src = ((size_t)rank * rows_per_rank + (size_t)sl * stripe_rows + rin) * width + x;
+    image[i] = packed[src];
+  }
+}
+
+}  // namespace
+
+void rt_launch_render(const RtRenderParams& p, int layout, bool count_work, int n_cu, hipStream_t s) {
+  const uint32_t waves = p.n_tiles;
+  uint32_t blocks = (waves + (TBLK / 64) - 1) / (TBLK / 64);
+  const uint32_t cap = (uint32_t)n_cu * 4u;              // ~4 resident 256-thread blocks per CU
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  const size_t lds = (size_t)p.max_stack * TBLK * (sizeof(uint32_t) + sizeof(float));
+  dim3 g(blocks), b(TBLK);
+  if (layout == RT_LAYOUT_WIDE64) {
+    if (count_work) hipLaunchKernelGGL((k_render<RT_LAYOUT_WIDE64, true>), g, b, lds, s, p);
+    else hipLaunchKernelGGL((k_render<RT_LAYOUT_WIDE64, false>), g, b, lds, s, p);
+  } else {
+    if (count_work) hipLaunchKernelGGL((k_render<RT_LAYOUT_AOS32, true>), g, b, lds, s, p);
+    else hipLaunchKernelGGL((k_render<RT_LAYOUT_AOS32, false>), g, b, lds, s, p);
+  }
+}
+
+void rt_launch_deinterleave(const void* packed, void* image, uint32_t width, uint32_t height, uint32_t elem_bytes,
+                            int stripe_rows, int world, uint32_t rows_per_rank, hipStream_t s) {
+  const size_t n = (size_t)width * height;
+  int blocks = (int)((n + TBLK - 1) / TBLK);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  if (elem_bytes == 4)
+    hipLaunchKernelGGL((k_deinterleave<uint32_t>), dim3(blocks), dim3(TBLK), 0, s, (const uint32_t*)packed, (uint32_t*)image,
+                       width, height, stripe_rows, world, rows_per_rank);
+  else
+    hipLaunchKernelGGL((k_deinterleave<uint8_t>), dim3(blocks), dim3(TBLK), 0, s, (const uint8_t*)packed, (uint8_t*)image,
+                       width * elem_bytes, height, stripe_rows, world, rows_per_rank);
+}
