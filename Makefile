@@ -1,5 +1,5 @@
 # rtcore-mi355x — builds the product library, the CPU oracle (test infrastructure) and the C++ host.
-#   make            -> raytracer_amd/lib/librtcore.so, oracle/liboracle.so, build/rt_host
+#   make            -> raytracer_amd/lib/librtcore.so, oracle/liboracle.so, raytracer_amd/bin/rt_host
 #   make lib|oracle|host|clean
 HIPCC     ?= /opt/rocm/bin/hipcc
 ARCH      ?= gfx950
@@ -29,15 +29,15 @@ $(LIB): $(OBJS)
 oracle:
 	$(MAKE) -C oracle
 
-host: build/rt_host
+host: raytracer_amd/bin/rt_host
 
-build/rt_host: src/main.cpp include/rtcore.h $(LIB)
-	@mkdir -p build
+raytracer_amd/bin/rt_host: src/main.cpp include/rtcore.h $(LIB)
+	@mkdir -p raytracer_amd/bin
 	g++ -std=c++17 -O2 -Wall -Wextra -Iinclude src/main.cpp -o $@ -Lraytracer_amd/lib -lrtcore \
-	    -Wl,-rpath,'$$ORIGIN/../raytracer_amd/lib' -Wl,-rpath-link,/opt/rocm/lib
+	    -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath-link,/opt/rocm/lib
 
 clean:
-	rm -rf build raytracer_amd/lib/librtcore.so
+	rm -rf build raytracer_amd/lib/librtcore.so raytracer_amd/bin
 	$(MAKE) -C oracle clean
 
 .PHONY: all lib oracle host clean

@@ -443,6 +443,7 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
   std::memset(&p, 0, sizeof(p));
   p.nodes = ctx->bvh.nodes; p.tri_pos = ctx->bvh.tri_pos; p.tri_nor = ctx->bvh.tri_nor;
   p.wide = ctx->bvh.wide; p.tri_pre = ctx->bvh.tri_pre; p.root_ref = ctx->bvh.root_ref; p.leaf_shift = ctx->bvh.leaf_shift;
+  p.step_budget = ctx->bvh.n_nodes + 64u;
   std::memcpy(p.U, uniforms, sizeof(float) * 44);
   p.mode = opts->mode; p.gi_samples = opts->gi_samples; p.gi_bounces = opts->gi_bounces; p.soft_samples = opts->soft_samples;
   p.max_stack = opts->max_stack;

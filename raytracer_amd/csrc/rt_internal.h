@@ -42,6 +42,7 @@ struct RtRenderParams {
   const float4* tri_pre;
   uint32_t root_ref;
   int      leaf_shift;
+  uint32_t step_budget;            // n_nodes + 64
   float    U[44];
   int mode, gi_samples, gi_bounces, soft_samples, max_stack;
   uint32_t width, height;

