@@ -9,6 +9,8 @@ pytestmark = pytest.mark.gpu
 
 T_REL = 1e-5
 RGB_LSB = 1
+# plane.obj is a thin aircraft: look at it from above, scaled up, so ~30 % of the pixels hit
+PLANE_VIEW = dict(cam_pos=(0.0, 0.0, 1.3), rot_deg=(-90.0, 0.0, 0.0), scale=(2.5, 2.5, 2.5))
 
 
 def _compare(out, ref, tag):
@@ -35,7 +37,7 @@ COUNT_KEYS = ("rays_primary", "rays_shadow", "rays_bounce", "box_tests", "tri_te
 def test_plane_modes(gpu_ctx, oracle, rt, plane_mesh, mode, layout):
     ref_b = _scene(gpu_ctx, oracle, plane_mesh)
     w, h = (160, 96) if mode != "pt" else (96, 64)
-    U = rt.make_uniforms(w, h, cam_pos=(0.0, 0.0, 1.3))
+    U = rt.make_uniforms(w, h, **PLANE_VIEW)
     mid = dict(primary=0, shadow=1, pt=2)[mode]
     lay = dict(wide64=rt.LAYOUT_WIDE64, aos32=rt.LAYOUT_AOS32)[layout]
     out, st = gpu_ctx.render(U, rt.render_opts(mode=mid, layout=lay, flags=rt.FLAG_COUNT_WORK))
@@ -76,13 +78,12 @@ def test_s70k_primary_1080p(gpu_ctx, oracle, rt):
 def test_stack_overflow_drop_is_reproduced(gpu_ctx, oracle, rt, plane_mesh):
     """F9: with a tiny stack the far child is dropped; GPU and oracle must drop identically."""
     ref_b = _scene(gpu_ctx, oracle, plane_mesh)
-    U = rt.make_uniforms(128, 96, cam_pos=(0.0, 0.0, 1.3))
+    U = rt.make_uniforms(128, 96, **PLANE_VIEW)
     for ms in (2, 4, 12, 32):
         out, st = gpu_ctx.render(U, rt.render_opts(mode=rt.MODE_SHADOW, max_stack=ms, flags=rt.FLAG_COUNT_WORK))
         ref, rst = oracle.render(ref_b["nodes"], ref_b["tri_pos"], ref_b["tri_nor"], U, mode=1, max_stack=ms, n_threads=8)
         _compare(out, ref, f"stack{ms}")
         assert st["stack_drops"] == rst["stack_drops"]
-    assert rst["stack_drops"] == 0 or True
 
 
 def test_transformed_model_and_time(gpu_ctx, oracle, rt, plane_mesh):
@@ -99,7 +100,7 @@ def test_stripes_cover_the_image(gpu_ctx, rt, plane_mesh):
     gpu_ctx.set_mesh(plane_mesh)
     gpu_ctx.build_lbvh()
     w, h = 200, 150                       # deliberately not multiples of 8 / 16
-    U = rt.make_uniforms(w, h, cam_pos=(0.0, 0.0, 1.3))
+    U = rt.make_uniforms(w, h, **PLANE_VIEW)
     full, _ = gpu_ctx.render(U, rt.render_opts(mode=rt.MODE_SHADOW))
     for world in (2, 3, 8):
         acc = {k: np.zeros_like(v) for k, v in full.items()}
@@ -119,7 +120,7 @@ def test_stripes_cover_the_image(gpu_ctx, rt, plane_mesh):
 def test_imported_bvh_and_cache_file(gpu_ctx, oracle, rt, plane_mesh, tmp_path):
     """rt_set_bvh / rt_save_bvh / rt_load_bvh: an externally supplied flat BVH renders identically."""
     ref_b = _scene(gpu_ctx, oracle, plane_mesh)
-    U = rt.make_uniforms(128, 96, cam_pos=(0.0, 0.0, 1.3))
+    U = rt.make_uniforms(128, 96, **PLANE_VIEW)
     a, _ = gpu_ctx.render(U, rt.render_opts(mode=rt.MODE_SHADOW))
     p = str(tmp_path / "bvh.bin")
     gpu_ctx.save_bvh(p)
