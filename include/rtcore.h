@@ -115,6 +115,7 @@ typedef struct rt_build_stats {
   float ms_bounds, ms_morton, ms_sort, ms_tree, ms_refit, ms_pack, ms_total;  /* hipEvent times */
   uint32_t n_tri, n_nodes;
   uint64_t algorithmic_bytes;   /* 560 B x n_tri */
+  uint32_t refit_fallbacks;     /* times (this context) the fence-free refit hand-off failed verification and was redone fenced */
 } rt_build_stats;
 
 /* Replaces buildLBVH(raw, 1) + flattenForSSBO (script.js:729-730) with the Morton LBVH the
@@ -201,6 +202,9 @@ typedef struct rt_bvh_view {
   uint32_t n_nodes, n_tri;
 } rt_bvh_view;
 int rt_bvh_view_get(rt_ctx* ctx, rt_bvh_view* out);
+/* Copy the three flat buffers into caller-owned device memory of the same sizes (e.g. torch
+ * tensors that RCCL then broadcasts). Synchronous on the context stream. */
+int rt_bvh_export_device(rt_ctx* ctx, const rt_bvh_view* dst);
 /* Adopt caller-owned device buffers (filled by a broadcast) as this context's BVH and derive
  * the traversal layout from them.  The caller keeps the three buffers alive. */
 int rt_bvh_adopt_device(rt_ctx* ctx, const rt_bvh_view* view);

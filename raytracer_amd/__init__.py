@@ -237,6 +237,10 @@ class Context:
         self._chk(_L.rt_bvh_view_get(self._h, C.byref(v)))
         return v
 
+    def export_bvh_device(self, d_nodes, d_tri_pos, d_tri_nor, n_nodes, n_tri):
+        v = _abi.BvhView(d_nodes, 32 * n_nodes, d_tri_pos, 48 * n_tri, d_tri_nor, 48 * n_tri, n_nodes, n_tri)
+        self._chk(_L.rt_bvh_export_device(self._h, C.byref(v)))
+
     def adopt_bvh_device(self, d_nodes, d_tri_pos, d_tri_nor, n_nodes, n_tri):
         v = _abi.BvhView(d_nodes, 32 * n_nodes, d_tri_pos, 48 * n_tri, d_tri_nor, 48 * n_tri, n_nodes, n_tri)
         self._chk(_L.rt_bvh_adopt_device(self._h, C.byref(v)))

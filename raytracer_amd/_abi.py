@@ -22,7 +22,7 @@ SYMBOLS = [
     "rt_set_mesh", "rt_build_lbvh", "rt_get_bounds", "rt_get_morton", "rt_get_tri_order", "rt_get_counts",
     "rt_get_nodes", "rt_get_triangles", "rt_set_bvh", "rt_save_bvh", "rt_load_bvh",
     "rt_render_opts_default", "rt_render", "rt_render_device", "rt_packed_rows", "rt_deinterleave_device",
-    "rt_bvh_view_get", "rt_bvh_adopt_device", "rt_synchronize", "rt_stream",
+    "rt_bvh_view_get", "rt_bvh_export_device", "rt_bvh_adopt_device", "rt_synchronize", "rt_stream",
 ]
 
 
@@ -48,7 +48,7 @@ class Camera(C.Structure):
 
 class BuildStats(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("ms_bounds", "ms_morton", "ms_sort", "ms_tree", "ms_refit", "ms_pack", "ms_total")] + \
-               [("n_tri", C.c_uint32), ("n_nodes", C.c_uint32), ("algorithmic_bytes", C.c_uint64)]
+               [("n_tri", C.c_uint32), ("n_nodes", C.c_uint32), ("algorithmic_bytes", C.c_uint64), ("refit_fallbacks", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -109,6 +109,7 @@ def load():
         "rt_packed_rows": (u32, [u32, i32, i32, i32]),
         "rt_deinterleave_device": (C.c_int, [vp, vp, vp, u32, u32, u32, i32, i32, u32]),
         "rt_bvh_view_get": (C.c_int, [vp, C.POINTER(BvhView)]),
+        "rt_bvh_export_device": (C.c_int, [vp, C.POINTER(BvhView)]),
         "rt_bvh_adopt_device": (C.c_int, [vp, C.POINTER(BvhView)]),
         "rt_synchronize": (C.c_int, [vp]),
         "rt_stream": (vp, [vp]),

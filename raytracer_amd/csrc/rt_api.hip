@@ -46,6 +46,7 @@ struct rt_ctx {
   DevBuf<float> bounds_f;
   DevBuf<int32_t> child, parent;
   bool built = false;      // codes / order valid
+  uint32_t refit_fallbacks = 0;
 
   // BVH
   RtBvhDev bvh;
@@ -54,7 +55,7 @@ struct rt_ctx {
   bool have_bvh = false;
 
   // render scratch
-  DevBuf<uint32_t> r_tile_counter;
+  DevBuf<uint32_t> r_tile_counter, r_list;
   DevBuf<unsigned long long> r_stats;
   DevBuf<uint8_t> o_rgba;
   DevBuf<uint32_t> o_tri;
@@ -143,7 +144,7 @@ extern "C" void rt_destroy(rt_ctx* ctx) {
   ctx->child.release(); ctx->parent.release();
   ctx->own_nodes.release(); ctx->own_tri_pos.release(); ctx->own_tri_nor.release();
   ctx->wide.release(); ctx->tri_pre.release();
-  ctx->r_tile_counter.release(); ctx->r_stats.release(); ctx->o_rgba.release(); ctx->o_tri.release(); ctx->o_t.release();
+  ctx->r_tile_counter.release(); ctx->r_list.release(); ctx->r_stats.release(); ctx->o_rgba.release(); ctx->o_tri.release(); ctx->o_t.release();
   for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -218,13 +219,22 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
   HIPCHK(hipEventRecord(ctx->ev[3], s));
   rt_launch_karras(b, s);
   HIPCHK(hipEventRecord(ctx->ev[4], s));
-  rt_launch_refit(b, ctx->own_nodes.p, ctx->own_tri_pos.p, ctx->own_tri_nor.p, s);
+  rt_launch_refit(b, ctx->own_nodes.p, ctx->own_tri_pos.p, ctx->own_tri_nor.p, /*fenced=*/false, s);
   HIPCHK(hipEventRecord(ctx->ev[5], s));
   HIPCHK(hipGetLastError());
   uint32_t errw = 0;
   HIPCHK(hipMemcpyAsync(&errw, ctx->words.p + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
-  if (errw) return ctx->fail(RT_ERR_INTERNAL, "rt_build_lbvh: radix-sort look-back spin limit expired");
+  if (errw & 1u) return ctx->fail(RT_ERR_INTERNAL, "rt_build_lbvh: radix-sort look-back spin limit expired");
+  if (errw & 8u) {   // the write-through hand-off was caught stale by k_refit_verify: redo with full fences
+    ctx->refit_fallbacks += 1;
+    HIPCHK(hipMemsetAsync(ctx->words.p + 2, 0, sizeof(uint32_t), s));
+    rt_launch_refit(b, ctx->own_nodes.p, ctx->own_tri_pos.p, ctx->own_tri_nor.p, /*fenced=*/true, s);
+    HIPCHK(hipEventRecord(ctx->ev[5], s));
+    HIPCHK(hipMemcpyAsync(&errw, ctx->words.p + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (errw) return ctx->fail(RT_ERR_INTERNAL, "rt_build_lbvh: refit verification failed even with agent-scope fences");
+  }
 
   ctx->bvh = RtBvhDev();
   ctx->bvh.nodes = ctx->own_nodes.p; ctx->bvh.tri_pos = ctx->own_tri_pos.p; ctx->bvh.tri_nor = ctx->own_tri_nor.p;
@@ -246,6 +256,7 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
     out->ms_total = out->ms_bounds + out->ms_morton + out->ms_sort + out->ms_tree + out->ms_refit + out->ms_pack;
     out->n_tri = T; out->n_nodes = N;
     out->algorithmic_bytes = 560ull * T;
+    out->refit_fallbacks = ctx->refit_fallbacks;
   }
   return RT_OK;
 }
@@ -377,6 +388,20 @@ extern "C" int rt_bvh_view_get(rt_ctx* ctx, rt_bvh_view* out) {
   return RT_OK;
 }
 
+extern "C" int rt_bvh_export_device(rt_ctx* ctx, const rt_bvh_view* dst) {
+  NEED_BVH();
+  if (!dst || !dst->d_nodes || !dst->d_tri_pos || !dst->d_tri_nor) return ctx->fail(RT_ERR_INVALID, "rt_bvh_export_device: incomplete view");
+  const uint64_t nb = 32ull * ctx->bvh.n_nodes, tb = 48ull * ctx->bvh.n_tri;
+  if (dst->nodes_bytes < nb || dst->tri_pos_bytes < tb || dst->tri_nor_bytes < tb)
+    return ctx->fail(RT_ERR_INVALID, "rt_bvh_export_device: destination buffers too small");
+  DeviceGuard g(ctx->device);
+  HIPCHK(hipMemcpyAsync(dst->d_nodes, ctx->bvh.nodes, nb, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(dst->d_tri_pos, ctx->bvh.tri_pos, tb, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(dst->d_tri_nor, ctx->bvh.tri_nor, tb, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return RT_OK;
+}
+
 extern "C" int rt_bvh_adopt_device(rt_ctx* ctx, const rt_bvh_view* v) {
   if (!ctx) return RT_ERR_INVALID;
   if (!v || !v->d_nodes || !v->d_tri_pos || !v->d_tri_nor || v->n_nodes == 0 || v->n_tri == 0)
@@ -455,11 +480,14 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
   p.tiles_x = (p.width + 7) / 8;
   p.n_tiles = p.tiles_x * ((p.local_rows + 7) / 8);
   p.rgba8 = static_cast<uint8_t*>(d_rgba8); p.hit_tri = static_cast<uint32_t*>(d_hit_tri); p.hit_t = static_cast<float*>(d_hit_t);
-  HIPCHK(ctx->r_tile_counter.ensure(1));
+  HIPCHK(ctx->r_tile_counter.ensure(2));
   HIPCHK(ctx->r_stats.ensure(8));
-  p.tile_counter = ctx->r_tile_counter.p; p.stats = ctx->r_stats.p;
+  HIPCHK(ctx->r_list.ensure((size_t)p.local_rows * p.width));
+  p.tile_counter = ctx->r_tile_counter.p; p.list_count = ctx->r_tile_counter.p + 1; p.list = ctx->r_list.p;
+  p.stats = ctx->r_stats.p;
   hipStream_t s = ctx->stream;
-  HIPCHK(hipMemsetAsync(p.tile_counter, 0, sizeof(uint32_t), s));
+  HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.tile_counter), (int)(rt_render_grid(ctx->n_cu) * 4u), 1, s));
+  HIPCHK(hipMemsetAsync(p.list_count, 0, sizeof(uint32_t), s));
   HIPCHK(hipMemsetAsync(p.stats, 0, sizeof(unsigned long long) * 8, s));
   if (p.n_tiles > 0) {
     if (out) HIPCHK(hipEventRecord(ctx->ev[0], s));

@@ -301,6 +301,51 @@ __global__ __launch_bounds__(BLK) void k_karras(const uint32_t* __restrict__ k, 
 }
 
 // ---------------------------------------------------------------- leaves + bottom-up refit
+// Node records are handed from the first arrival at a parent to the second one, which may run
+// on another CU / XCD (L1 per CU, L2 per XCD are not coherent).  Two forms:
+//   FENCED = false (default): every record is written with 8-byte agent-scope (sc1, write-
+//     through) stores, drained with s_waitcnt vmcnt(0) before the arrival counter is bumped;
+//     the second arrival reads the sibling with 8-byte agent-scope (sc1) loads.  No L2
+//     write-back / L1 invalidate per hand-off (MI355X_MICROARCH.md "Valid forms", row 1).
+//     k_refit_verify re-derives every internal box from its children afterwards; on any
+//     mismatch the host re-runs the FENCED form.
+//   FENCED = true: plain stores + __threadfence() (release / acquire at agent scope) around
+//     the counter: the textbook form, ~80x slower here (buffer_wbl2 + buffer_inv per arrival).
+RT_DEV unsigned long long pack2f(float a, float b) {
+  return (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
+}
+template <bool FENCED>
+RT_DEV void store_node(float* nodes, int idx, V3 mn, float a, V3 mx, float b) {
+  if (FENCED) {
+    float4* nd = reinterpret_cast<float4*>(nodes) + 2 * (size_t)idx;
+    nd[0] = make_float4(mn.x, mn.y, mn.z, a);
+    nd[1] = make_float4(mx.x, mx.y, mx.z, b);
+  } else {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(nodes) + 4 * (size_t)idx;
+    __hip_atomic_store(q + 0, pack2f(mn.x, mn.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, pack2f(mn.z, a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 2, pack2f(mx.x, mx.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 3, pack2f(mx.z, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+template <bool FENCED>
+RT_DEV void load_box(const float* nodes, int idx, V3& mn, V3& mx) {
+  if (FENCED) {
+    const float4* nd = reinterpret_cast<const float4*>(nodes) + 2 * (size_t)idx;
+    const float4 s0 = nd[0], s1 = nd[1];
+    mn = xyz(s0); mx = xyz(s1);
+  } else {
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(nodes) + 4 * (size_t)idx;
+    const unsigned long long w0 = __hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long w1 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long w2 = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long w3 = __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mn = v3(__uint_as_float((uint32_t)w0), __uint_as_float((uint32_t)(w0 >> 32)), __uint_as_float((uint32_t)w1));
+    mx = v3(__uint_as_float((uint32_t)w2), __uint_as_float((uint32_t)(w2 >> 32)), __uint_as_float((uint32_t)w3));
+  }
+}
+
+template <bool FENCED>
 __global__ __launch_bounds__(BLK) void k_refit(const float* __restrict__ pos, const float* __restrict__ nor,
                                                const uint32_t* __restrict__ vidx, const uint32_t* __restrict__ nidx,
                                                const uint32_t* __restrict__ order, uint32_t n_tri,
@@ -324,25 +369,40 @@ __global__ __launch_bounds__(BLK) void k_refit(const float* __restrict__ pos, co
   V3 mn = v3(fminf(fminf(p[0].x, p[1].x), p[2].x), fminf(fminf(p[0].y, p[1].y), p[2].y), fminf(fminf(p[0].z, p[1].z), p[2].z));
   V3 mx = v3(fmaxf(fmaxf(p[0].x, p[1].x), p[2].x), fmaxf(fmaxf(p[0].y, p[1].y), p[2].y), fmaxf(fmaxf(p[0].z, p[1].z), p[2].z));
   int cur = (int)(n_tri - 1) + (int)j;
-  float4* nd = reinterpret_cast<float4*>(nodes);
-  nd[2 * (size_t)cur + 0] = make_float4(mn.x, mn.y, mn.z, (float)j);      // A = tri_start (script.js:348,554)
-  nd[2 * (size_t)cur + 1] = make_float4(mx.x, mx.y, mx.z, -1.0f);         // B = -count
+  store_node<FENCED>(nodes, cur, mn, (float)j, mx, -1.0f);   // A = tri_start, B = -count (script.js:348,554,558)
   for (;;) {
     const int par = parent[cur];
     if (par < 0) break;
-    __threadfence();                                   // release this subtree's records (agent scope)
+    if (FENCED) __threadfence();                       // release this subtree's records (agent scope)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through stores have left this CU
     const uint32_t arrived = atomicAdd(&visit[par], 1u);
     if (arrived == 0) break;                           // the sibling's thread will finish this node
-    __threadfence();                                   // acquire the sibling's record
+    if (FENCED) __threadfence();                       // acquire the sibling's record
     const int c0 = child[2 * par + 0], c1 = child[2 * par + 1];
     const int sib = (c0 == cur) ? c1 : c0;
-    const float4 s0 = nd[2 * (size_t)sib + 0], s1 = nd[2 * (size_t)sib + 1];
-    mn = v3(fminf(mn.x, s0.x), fminf(mn.y, s0.y), fminf(mn.z, s0.z));
-    mx = v3(fmaxf(mx.x, s1.x), fmaxf(mx.y, s1.y), fmaxf(mx.z, s1.z));
-    nd[2 * (size_t)par + 0] = make_float4(mn.x, mn.y, mn.z, (float)c0);   // indices as f32 values (F11)
-    nd[2 * (size_t)par + 1] = make_float4(mx.x, mx.y, mx.z, (float)c1);
+    V3 smn, smx;
+    load_box<FENCED>(nodes, sib, smn, smx);
+    mn = v3(fminf(mn.x, smn.x), fminf(mn.y, smn.y), fminf(mn.z, smn.z));
+    mx = v3(fmaxf(mx.x, smx.x), fmaxf(mx.y, smx.y), fmaxf(mx.z, smx.z));
+    store_node<FENCED>(nodes, par, mn, (float)c0, mx, (float)c1);   // indices as f32 values (F11)
     cur = par;
   }
+}
+
+// every internal box must equal the union of its children's boxes, every slot must be filled
+__global__ __launch_bounds__(BLK) void k_refit_verify(const float* __restrict__ nodes, uint32_t n_tri,
+                                                      const int32_t* __restrict__ child, const uint32_t* __restrict__ visit,
+                                                      uint32_t* err) {
+  const uint32_t i = blockIdx.x * BLK + threadIdx.x;
+  if (i + 1 >= n_tri) return;
+  const float4* nd = reinterpret_cast<const float4*>(nodes);
+  const int c0 = child[2 * i + 0], c1 = child[2 * i + 1];
+  const float4 a = nd[2 * (size_t)i], b = nd[2 * (size_t)i + 1];
+  const float4 a0 = nd[2 * (size_t)c0], b0 = nd[2 * (size_t)c0 + 1], a1 = nd[2 * (size_t)c1], b1 = nd[2 * (size_t)c1 + 1];
+  bool ok = (visit[i] == 2u) && (a.w == (float)c0) && (b.w == (float)c1);
+  ok = ok && a.x == fminf(a0.x, a1.x) && a.y == fminf(a0.y, a1.y) && a.z == fminf(a0.z, a1.z);
+  ok = ok && b.x == fmaxf(b0.x, b1.x) && b.y == fmaxf(b0.y, b1.y) && b.z == fmaxf(b0.z, b1.z);
+  if (!ok) atomicOr(err, 8u);
 }
 
 // ---------------------------------------------------------------- traversal layout
@@ -426,10 +486,17 @@ void rt_launch_karras(const RtBuildBuffers& b, hipStream_t s) {
   hipLaunchKernelGGL(k_karras, dim3((n_int + BLK - 1) / BLK), dim3(BLK), 0, s, b.keys_a, b.n_tri, b.child, b.parent);
 }
 
-void rt_launch_refit(const RtBuildBuffers& b, float* nodes, float* tri_pos, float* tri_nor, hipStream_t s) {
+void rt_launch_refit(const RtBuildBuffers& b, float* nodes, float* tri_pos, float* tri_nor, bool fenced, hipStream_t s) {
   if (b.n_tri > 1) (void)hipMemsetAsync(b.visit, 0, sizeof(uint32_t) * (b.n_tri - 1), s);
-  hipLaunchKernelGGL(k_refit, dim3((b.n_tri + BLK - 1) / BLK), dim3(BLK), 0, s, b.pos, b.nor, b.vidx, b.nidx, b.vals_a, b.n_tri,
-                     b.child, b.parent, b.visit, nodes, tri_pos, tri_nor);
+  const dim3 g((b.n_tri + BLK - 1) / BLK), blk(BLK);
+  if (fenced)
+    hipLaunchKernelGGL(k_refit<true>, g, blk, 0, s, b.pos, b.nor, b.vidx, b.nidx, b.vals_a, b.n_tri, b.child, b.parent, b.visit,
+                       nodes, tri_pos, tri_nor);
+  else
+    hipLaunchKernelGGL(k_refit<false>, g, blk, 0, s, b.pos, b.nor, b.vidx, b.nidx, b.vals_a, b.n_tri, b.child, b.parent, b.visit,
+                       nodes, tri_pos, tri_nor);
+  if (b.n_tri > 1)   // sets bit 8 of err_flag on any inconsistency
+    hipLaunchKernelGGL(k_refit_verify, dim3((b.n_tri - 1 + BLK - 1) / BLK), blk, 0, s, nodes, b.n_tri, b.child, b.visit, b.err_flag);
 }
 
 // root_ref / err words live right behind the bounds words: see rt_api.hip (scratch[0], scratch[1])

@@ -51,7 +51,9 @@ struct RtRenderParams {
   uint8_t*  rgba8;     // packed local rows
   uint32_t* hit_tri;
   float*    hit_t;
-  uint32_t* tile_counter;          // zeroed before launch
+  uint32_t* tile_counter;          // chunk queue head of phase B: preset to the number of waves of the persistent grid
+  uint32_t* list;                  // [local_rows*width] compacted pixel ids (phase A -> phase B)
+  uint32_t* list_count;            // zeroed before launch
   unsigned long long* stats;       // [8]: rays_primary, rays_shadow, rays_bounce, box, tri, hitupd, pixels, drops
 };
 
@@ -79,11 +81,12 @@ void rt_launch_bounds(const RtBuildBuffers& b, hipStream_t s);
 void rt_launch_morton(const RtBuildBuffers& b, hipStream_t s);
 void rt_launch_sort(const RtBuildBuffers& b, hipStream_t s);      // result in keys_a / vals_a
 void rt_launch_karras(const RtBuildBuffers& b, hipStream_t s);
-void rt_launch_refit(const RtBuildBuffers& b, float* nodes, float* tri_pos, float* tri_nor, hipStream_t s);
+void rt_launch_refit(const RtBuildBuffers& b, float* nodes, float* tri_pos, float* tri_nor, bool fenced, hipStream_t s);
 // derive the traversal layout from the interchange buffers; writes the root ref / error bits
 void rt_launch_pack_impl(const RtBvhDev& bvh, uint32_t* d_root_ref, uint32_t* d_err, hipStream_t s);
 
 // ---------------------------------------------------------------- traversal (rt_trace.hip)
+uint32_t rt_render_grid(int n_cu);   // blocks of the persistent phase-B grid
 void rt_launch_render(const RtRenderParams& p, int layout, bool count_work, int n_cu, hipStream_t s);
 void rt_launch_deinterleave(const void* packed, void* image, uint32_t width, uint32_t height, uint32_t elem_bytes,
                             int stripe_rows, int world, uint32_t rows_per_rank, hipStream_t s);

@@ -333,27 +333,37 @@ RT_DEV uint32_t unorm8(float c) { return sat_u32(floorf(fminf(fmaxf(c, 0.0f), 1.
 
 struct PixelOut { uint32_t rgba; uint32_t tri; float t; };
 
-// web/compute.wgsl:349-410 + :419-444
-template <int LAYOUT, bool COUNT>
-RT_DEV PixelOut shade_pixel(const Scene& S, const Shade& sh, const float* U, uint32_t gx, uint32_t gy, uint32_t w, uint32_t h,
-                            float time_h, Work& W, RayCount& R) {
+struct PrimaryRay { V3 ro, rd, inv, light; uint32_t pixelIndex; };
+
+// web/compute.wgsl:419-442 (cs_main) + :351-361 (world -> object space)
+RT_DEV PrimaryRay primary_ray(const float* U, uint32_t gx, uint32_t gy, uint32_t w, uint32_t h) {
   const float uvx = ((float)gx + 0.5f) / (float)w, uvy = ((float)gy + 0.5f) / (float)h;
   const V3 ro_w = v3(U[0], U[1], U[2]);
   const float sx = __fmaf_rn(uvx, 2.0f, -1.0f), sy = __fmaf_rn(uvy, 2.0f, -1.0f);
   const V3 rd_w = normalize3(fma3(v3(U[8], U[9], U[10]), sx, fma3(v3(U[12], U[13], U[14]), sy, v3(U[16], U[17], U[18]))));
   const float px = fminf(fmaxf(uvx * (float)w, 0.0f), (float)(w - 1));
   const float py = fminf(fmaxf(uvy * (float)h, 0.0f), (float)(h - 1));
-  const uint32_t pixelIndex = sat_u32(py) * w + sat_u32(px);
-
+  PrimaryRay r;
+  r.pixelIndex = sat_u32(py) * w + sat_u32(px);
   const float* model = U + 20;
-  const V3 ro_os = mat_mul4(model, ro_w.x, ro_w.y, ro_w.z, 1.0f);
-  const V3 rd_os = normalize3(mat_mul3(model, rd_w));
-  const V3 invRd = rcp3(rd_os);
-  const V3 light_os = mat_mul4(model, U[4], U[5], U[6], U[7]);
+  r.ro = mat_mul4(model, ro_w.x, ro_w.y, ro_w.z, 1.0f);
+  r.rd = normalize3(mat_mul3(model, rd_w));
+  r.inv = rcp3(r.rd);
+  r.light = mat_mul4(model, U[4], U[5], U[6], U[7]);
+  return r;
+}
+
+// web/compute.wgsl:349-410
+template <int LAYOUT, bool COUNT>
+RT_DEV PixelOut shade_pixel(const Scene& S, const Shade& sh, const float* U, uint32_t gx, uint32_t gy, uint32_t w, uint32_t h,
+                            float time_h, Work& W, RayCount& R) {
+  const PrimaryRay pr = primary_ray(U, gx, gy, w, h);
+  const V3 ro_os = pr.ro, rd_os = pr.rd, light_os = pr.light;
+  const uint32_t pixelIndex = pr.pixelIndex;
 
   PixelOut out;
   R.primary += 1;
-  const Hit hit0 = closest<LAYOUT, COUNT>(S, ro_os, rd_os, invRd, 1e20f, W);
+  const Hit hit0 = closest<LAYOUT, COUNT>(S, ro_os, rd_os, pr.inv, 1e20f, W);
   out.tri = hit0.tri; out.t = hit0.t;
   if (hit0.t >= 1e19f) { out.rgba = 0xFF000000u; out.tri = 0xFFFFFFFFu; return out; }   // (0,0,0,1)
 
@@ -399,6 +409,70 @@ RT_DEV uint32_t wave_sum_u32(uint32_t v) {
   return v;
 }
 
+RT_DEV uint32_t local_to_global_row(const RtRenderParams& p, uint32_t lrow) {
+  if (p.stripe_rows <= 0) return lrow;
+  const uint32_t sl = lrow / (uint32_t)p.stripe_rows, rin = lrow % (uint32_t)p.stripe_rows;
+  return (sl * (uint32_t)p.stripe_world + (uint32_t)p.stripe_rank) * (uint32_t)p.stripe_rows + rin;
+}
+
+template <bool COUNT>
+RT_DEV void flush_stats(const RtRenderParams& p, int lane, const RayCount& R, const Work& W, uint32_t pixels) {
+  uint32_t c[8] = {R.primary, R.shadow, R.bounce, W.box, W.tri, W.hit, pixels, W.drops};   // one atomic per wave and counter
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (!COUNT && (k == 3 || k == 4 || k == 5 || k == 7)) continue;
+    const uint32_t s = wave_sum_u32(c[k]);
+    if (lane == 0 && s) atomicAdd(&p.stats[k], (unsigned long long)s);
+  }
+}
+
+// Phase A — cull + compact.  One lane per pixel of an 8x8 tile, tiles dealt to waves round-
+// robin (no queue).  A primary ray that misses the root box (compute.wgsl:275 on node 0) can
+// never hit anything: its pixel is final here ((0,0,0,1), compute.wgsl:365-367).  Every other
+// pixel is appended to a work list (one wave-aggregated atomic per tile), tile-major, so that
+// phase B runs with all 64 lanes on rays that actually enter the tree.
+template <bool COUNT>
+__global__ __launch_bounds__(TBLK) void k_cull(const RtRenderParams p) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = blockIdx.x * (TBLK / 64) + (threadIdx.x >> 6), n_waves = gridDim.x * (TBLK / 64);
+  const float4 ra = reinterpret_cast<const float4*>(p.nodes)[0], rb = reinterpret_cast<const float4*>(p.nodes)[1];
+  Work W; W.box = W.tri = W.hit = W.drops = 0;
+  RayCount R; R.primary = R.shadow = R.bounce = 0;
+  uint32_t pixels = 0;
+  for (uint32_t tile = wave; tile < p.n_tiles; tile += n_waves) {
+    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const uint32_t x = tx * 8u + (uint32_t)(lane & 7), lrow = ty * 8u + (uint32_t)(lane >> 3);
+    const uint32_t y = local_to_global_row(p, lrow);
+    const bool inside = (x < p.width && lrow < p.local_rows && y < p.height);
+    bool enters = false;
+    const uint32_t idx = lrow * p.width + x;
+    if (inside) {
+      const PrimaryRay pr = primary_ray(p.U, x, y, p.width, p.height);
+      float tn, tf; slab(pr.ro, pr.inv, xyz(ra), xyz(rb), tn, tf);
+      enters = box_hit(tn, tf, 1e20f);
+      if (!enters) {
+        if (p.rgba8) reinterpret_cast<uint32_t*>(p.rgba8)[idx] = 0xFF000000u;
+        if (p.hit_tri) p.hit_tri[idx] = 0xFFFFFFFFu;
+        if (p.hit_t) p.hit_t[idx] = 1e20f;
+        R.primary += 1; pixels += 1;
+        if (COUNT) W.box += 1;
+      }
+    }
+    const unsigned long long m = __ballot(enters);
+    if (m) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(p.list_count, (uint32_t)__popcll(m));
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+      if (enters) p.list[base + (uint32_t)__popcll(m & lt)] = idx;
+    }
+  }
+  flush_stats<COUNT>(p, lane, R, W, pixels);
+}
+
+// Phase B — persistent-thread traversal + shading over the compacted pixel list.  Each wave
+// owns chunk `wave` first, then pulls further 64-pixel chunks from a global atomic counter
+// (pre-set to the number of waves) until the list is drained.
 template <int LAYOUT, bool COUNT>
 __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -419,36 +493,26 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
   Work W; W.box = W.tri = W.hit = W.drops = 0;
   RayCount R; R.primary = R.shadow = R.bounce = 0;
   uint32_t pixels = 0;
-
-  for (;;) {                                             // persistent: every wave drains the tile queue
-    uint32_t tile = 0;
-    if (lane == 0) tile = atomicAdd(p.tile_counter, 1u);
-    tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
-    if (tile >= p.n_tiles) break;
-    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
-    const uint32_t x = tx * 8u + (uint32_t)(lane & 7), lrow = ty * 8u + (uint32_t)(lane >> 3);
-    uint32_t y = lrow;
-    if (p.stripe_rows > 0) {
-      const uint32_t sl = lrow / (uint32_t)p.stripe_rows, rin = lrow % (uint32_t)p.stripe_rows;
-      y = (sl * (uint32_t)p.stripe_world + (uint32_t)p.stripe_rank) * (uint32_t)p.stripe_rows + rin;
-    }
-    if (x < p.width && lrow < p.local_rows && y < p.height) {
+  const uint32_t n_list = *p.list_count;                 // written by k_cull (previous launch on this stream)
+  const uint32_t n_chunks = (n_list + 63u) / 64u;
+  uint32_t chunk = blockIdx.x * (TBLK / 64) + (threadIdx.x >> 6);
+  while (chunk < n_chunks) {
+    const uint32_t li = chunk * 64u + (uint32_t)lane;
+    if (li < n_list) {
+      const uint32_t idx = p.list[li];
+      const uint32_t x = idx % p.width, lrow = idx / p.width;
+      const uint32_t y = local_to_global_row(p, lrow);
       const PixelOut o = shade_pixel<LAYOUT, COUNT>(S, sh, p.U, x, y, p.width, p.height, time_h, W, R);
-      const size_t idx = (size_t)lrow * p.width + x;
       if (p.rgba8) reinterpret_cast<uint32_t*>(p.rgba8)[idx] = o.rgba;
       if (p.hit_tri) p.hit_tri[idx] = o.tri;
       if (p.hit_t) p.hit_t[idx] = o.t;
       pixels += 1;
     }
+    uint32_t next = 0;
+    if (lane == 0) next = atomicAdd(p.tile_counter, 1u);
+    chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
   }
-  // one atomic per wave and counter
-  uint32_t c[8] = {R.primary, R.shadow, R.bounce, W.box, W.tri, W.hit, pixels, W.drops};
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    if (!COUNT && (k == 3 || k == 4 || k == 5 || k == 7)) continue;
-    const uint32_t s = wave_sum_u32(c[k]);
-    if (lane == 0 && s) atomicAdd(&p.stats[k], (unsigned long long)s);
-  }
+  flush_stats<COUNT>(p, lane, R, W, pixels);
 }
 
 template <typename T>
@@ -466,14 +530,19 @@ __global__ __launch_bounds__(TBLK) void k_deinterleave(const T* __restrict__ pac
 
 }  // namespace
 
+uint32_t rt_render_grid(int n_cu) { return (uint32_t)n_cu * 4u; }   // ~4 resident 256-thread blocks per CU (128 VGPRs)
+
 void rt_launch_render(const RtRenderParams& p, int layout, bool count_work, int n_cu, hipStream_t s) {
-  const uint32_t waves = p.n_tiles;
-  uint32_t blocks = (waves + (TBLK / 64) - 1) / (TBLK / 64);
-  const uint32_t cap = (uint32_t)n_cu * 4u;              // ~4 resident 256-thread blocks per CU
-  if (blocks > cap) blocks = cap;
-  if (blocks < 1) blocks = 1;
+  const dim3 b(TBLK);
+  // phase A: cull + compact (tile_counter / list_count are reset by the caller)
+  uint32_t cull_blocks = (p.n_tiles + (TBLK / 64) - 1) / (TBLK / 64);
+  if (cull_blocks > (uint32_t)n_cu * 8u) cull_blocks = (uint32_t)n_cu * 8u;
+  if (cull_blocks < 1) cull_blocks = 1;
+  if (count_work) hipLaunchKernelGGL((k_cull<true>), dim3(cull_blocks), b, 0, s, p);
+  else hipLaunchKernelGGL((k_cull<false>), dim3(cull_blocks), b, 0, s, p);
+  // phase B: persistent traversal over the compacted list
+  const dim3 g(rt_render_grid(n_cu));
   const size_t lds = (size_t)p.max_stack * TBLK * (sizeof(uint32_t) + sizeof(float));
-  dim3 g(blocks), b(TBLK);
   if (layout == RT_LAYOUT_WIDE64) {
     if (count_work) hipLaunchKernelGGL((k_render<RT_LAYOUT_WIDE64, true>), g, b, lds, s, p);
     else hipLaunchKernelGGL((k_render<RT_LAYOUT_WIDE64, false>), g, b, lds, s, p);

@@ -1,0 +1,91 @@
+"""Multi-GPU host logic: one process per GPU, torch.distributed (RCCL) for
+the two exchange steps the path really has —
+  * BVH replication: built once on rank 0, the three flat buffers are broadcast over xGMI;
+  * framebuffer gather: each rank renders its 16-row stripes (stripe s -> rank s % world) into
+    a PACKED buffer; all_gather of the equal-sized packed buffers + one de-interleave kernel.
+Pixels are independent: there is no collective inside the traversal itself.
+
+torch is plumbing only (device buffers + collectives); compute is behind the C ABI.  The
+`backend` object abstracts "render my packed stripes" / "de-interleave" so that the
+world_size-2 gloo tests can drive the same host logic on CPU with the oracle as backend.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import packed_rows, render_opts
+
+STRIPE_ROWS = 16
+
+
+def rows_per_rank(height, world, stripe_rows=STRIPE_ROWS):
+    """Packed-buffer height every rank allocates: rank 0 always owns the most rows."""
+    return packed_rows(height, stripe_rows, 0, world)
+
+
+def stripe_rows_of(height, rank, world, stripe_rows=STRIPE_ROWS):
+    """Global row numbers owned by `rank`, in packed order."""
+    ys = [y for y in range(height) if (y // stripe_rows) % world == rank]
+    return np.asarray(ys, dtype=np.int64)
+
+
+class GpuBackend:
+    """Renders through librtcore.so into torch-owned device buffers (no host copies)."""
+
+    def __init__(self, ctx, device):
+        self.ctx, self.device = ctx, device
+
+    def alloc(self, rows, width):
+        return torch.zeros((rows, width), dtype=torch.int32, device=self.device)
+
+    def render_packed(self, U, opts, packed):
+        st = self.ctx.render_device(U, opts, d_rgba8=packed.data_ptr(), want_stats=True)   # syncs the context stream
+        return st
+
+    def deinterleave(self, gathered, image, width, height, world, rpr):
+        self.ctx.deinterleave_device(gathered.data_ptr(), image.data_ptr(), width, height, 4, STRIPE_ROWS, world, rpr)
+        self.ctx.synchronize()
+
+
+def replicate_bvh(ctx, rank, world, device):
+    """Broadcast rank 0's flat BVH (nodes, triPos, triNor) and adopt it on every other rank.
+    Returns the tensors that back the adopted BVH (keep them alive)."""
+    meta = torch.zeros(2, dtype=torch.int64, device=device)
+    if rank == 0:
+        T, N = ctx.counts()
+        meta[0], meta[1] = T, N
+    dist.broadcast(meta, 0)
+    T, N = int(meta[0]), int(meta[1])
+    bufs = [torch.empty(32 * N, dtype=torch.uint8, device=device), torch.empty(48 * T, dtype=torch.uint8, device=device),
+            torch.empty(48 * T, dtype=torch.uint8, device=device)]
+    if rank == 0:
+        ctx.export_bvh_device(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), N, T)
+    for b in bufs:                      # three large broadcasts (32 B x N, 48 B x T, 48 B x T)
+        dist.broadcast(b, 0)
+    torch.cuda.synchronize(device)
+    if rank != 0:
+        ctx.adopt_bvh_device(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), N, T)
+    return bufs
+
+
+class ShardedFrame:
+    """One frame sharded as image-space stripes over `world` ranks and gathered on every rank."""
+
+    def __init__(self, backend, width, height, rank, world, base_opts=None):
+        self.b, self.w, self.h, self.rank, self.world = backend, width, height, rank, world
+        self.rpr = rows_per_rank(height, world) if world > 1 else height
+        o = base_opts or render_opts()
+        self.opts = render_opts(mode=o.mode, gi_samples=o.gi_samples, gi_bounces=o.gi_bounces, soft_samples=o.soft_samples,
+                                max_stack=o.max_stack, layout=o.layout, flags=o.flags,
+                                stripe_rows=STRIPE_ROWS if world > 1 else 0, stripe_rank=rank, stripe_world=world)
+        self.packed = backend.alloc(self.rpr, width)
+        self.gathered = backend.alloc(self.rpr * world, width) if world > 1 else None
+        self.image = backend.alloc(height, width) if world > 1 else self.packed
+
+    def step(self, U):
+        """Render my stripes, gather all stripes, de-interleave.  Returns this rank's render stats."""
+        st = self.b.render_packed(U, self.opts, self.packed)
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.gathered, self.packed)
+            self.b.deinterleave(self.gathered, self.image, self.w, self.h, self.world, self.rpr)
+        return st
