@@ -480,14 +480,17 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
   p.tiles_x = (p.width + 7) / 8;
   p.n_tiles = p.tiles_x * ((p.local_rows + 7) / 8);
   p.rgba8 = static_cast<uint8_t*>(d_rgba8); p.hit_tri = static_cast<uint32_t*>(d_hit_tri); p.hit_t = static_cast<float*>(d_hit_t);
-  HIPCHK(ctx->r_tile_counter.ensure(2));
-  HIPCHK(ctx->r_stats.ensure(8));
+  const uint32_t cull_blocks = rt_cull_blocks(p.n_tiles);
+  HIPCHK(ctx->r_tile_counter.ensure(rt_shard_words() + 32 + cull_blocks));
+  HIPCHK(ctx->r_stats.ensure(8 + (size_t)rt_render_grid(ctx->n_cu) * 8 + p.n_tiles));
   HIPCHK(ctx->r_list.ensure((size_t)p.local_rows * p.width));
-  p.tile_counter = ctx->r_tile_counter.p; p.list_count = ctx->r_tile_counter.p + 1; p.list = ctx->r_list.p;
-  p.stats = ctx->r_stats.p;
+  p.shard_heads = ctx->r_tile_counter.p; p.list_count = ctx->r_tile_counter.p + rt_shard_words();
+  p.block_total = ctx->r_tile_counter.p + rt_shard_words() + 32;
+  p.list = ctx->r_list.p;
+  p.stats = ctx->r_stats.p; p.stats_partial = ctx->r_stats.p + 8;
+  p.masks = ctx->r_stats.p + 8 + (size_t)rt_render_grid(ctx->n_cu) * 8;
   hipStream_t s = ctx->stream;
-  HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.tile_counter), (int)(rt_render_grid(ctx->n_cu) * 4u), 1, s));
-  HIPCHK(hipMemsetAsync(p.list_count, 0, sizeof(uint32_t), s));
+  HIPCHK(hipMemsetAsync(p.shard_heads, 0, sizeof(uint32_t) * (rt_shard_words() + 32), s));
   HIPCHK(hipMemsetAsync(p.stats, 0, sizeof(unsigned long long) * 8, s));
   if (p.n_tiles > 0) {
     if (out) HIPCHK(hipEventRecord(ctx->ev[0], s));

@@ -51,10 +51,13 @@ struct RtRenderParams {
   uint8_t*  rgba8;     // packed local rows
   uint32_t* hit_tri;
   float*    hit_t;
-  uint32_t* tile_counter;          // chunk queue head of phase B: preset to the number of waves of the persistent grid
+  uint32_t* shard_heads;           // [rt_shard_words()] phase-B queue heads, one per 128-byte line; zeroed before launch
+  unsigned long long* masks;       // [n_tiles] per-tile ballot of pixels whose primary ray enters the root box
+  uint32_t* block_total;           // [rt_cull_blocks(n_tiles)]
   uint32_t* list;                  // [local_rows*width] compacted pixel ids (phase A -> phase B)
-  uint32_t* list_count;            // zeroed before launch
+  uint32_t* list_count;            // written by k_compact
   unsigned long long* stats;       // [8]: rays_primary, rays_shadow, rays_bounce, box, tri, hitupd, pixels, drops
+  unsigned long long* stats_partial;   // [rt_render_grid()*8] per-block partials of phase B
 };
 
 // ---------------------------------------------------------------- build pipeline (rt_build.hip)
@@ -87,6 +90,8 @@ void rt_launch_pack_impl(const RtBvhDev& bvh, uint32_t* d_root_ref, uint32_t* d_
 
 // ---------------------------------------------------------------- traversal (rt_trace.hip)
 uint32_t rt_render_grid(int n_cu);   // blocks of the persistent phase-B grid
+uint32_t rt_cull_blocks(uint32_t n_tiles);
+uint32_t rt_shard_words();
 void rt_launch_render(const RtRenderParams& p, int layout, bool count_work, int n_cu, hipStream_t s);
 void rt_launch_deinterleave(const void* packed, void* image, uint32_t width, uint32_t height, uint32_t elem_bytes,
                             int stripe_rows, int world, uint32_t rows_per_rank, hipStream_t s);

@@ -415,64 +415,139 @@ RT_DEV uint32_t local_to_global_row(const RtRenderParams& p, uint32_t lrow) {
   return (sl * (uint32_t)p.stripe_world + (uint32_t)p.stripe_rank) * (uint32_t)p.stripe_rows + rin;
 }
 
+// Per-block partial counters, plain stores into the block's own slot (a same-address atomic per
+// wave costs ~12 ns each and serialises: 8192 waves x 2 counters were ~0.2 ms of a 0.36 ms launch).
 template <bool COUNT>
 RT_DEV void flush_stats(const RtRenderParams& p, int lane, const RayCount& R, const Work& W, uint32_t pixels) {
-  uint32_t c[8] = {R.primary, R.shadow, R.bounce, W.box, W.tri, W.hit, pixels, W.drops};   // one atomic per wave and counter
+  __shared__ uint32_t s_part[TBLK / 64][8];
+  uint32_t c[8] = {R.primary, R.shadow, R.bounce, W.box, W.tri, W.hit, pixels, W.drops};
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    if (!COUNT && (k == 3 || k == 4 || k == 5 || k == 7)) continue;
-    const uint32_t s = wave_sum_u32(c[k]);
-    if (lane == 0 && s) atomicAdd(&p.stats[k], (unsigned long long)s);
+    const uint32_t s = (!COUNT && (k == 3 || k == 4 || k == 5 || k == 7)) ? 0u : wave_sum_u32(c[k]);
+    if (lane == 0) s_part[threadIdx.x >> 6][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    unsigned long long t = 0;
+    for (int w = 0; w < TBLK / 64; ++w) t += s_part[w][threadIdx.x];
+    p.stats_partial[(size_t)blockIdx.x * 8 + threadIdx.x] = t;
   }
 }
 
-// Phase A — cull + compact.  One lane per pixel of an 8x8 tile, tiles dealt to waves round-
-// robin (no queue).  A primary ray that misses the root box (compute.wgsl:275 on node 0) can
-// never hit anything: its pixel is final here ((0,0,0,1), compute.wgsl:365-367).  Every other
-// pixel is appended to a work list (one wave-aggregated atomic per tile), tile-major, so that
-// phase B runs with all 64 lanes on rays that actually enter the tree.
-template <bool COUNT>
+// stats[k] = sum of the phase-B block partials; pixels culled in phase A never reach phase B:
+// each of them is one primary ray, one root-box test, one pixel.
+__global__ void k_stats_final(const RtRenderParams p, uint32_t n_blocks, uint32_t n_inside, int count_work) {
+  __shared__ unsigned long long s_sum[8][32];
+  const int k = threadIdx.x & 7, part = threadIdx.x >> 3;     // 256 threads: 8 counters x 32 strided readers
+  unsigned long long t = 0;
+  for (uint32_t b = part; b < n_blocks; b += 32) t += p.stats_partial[(size_t)b * 8 + k];
+  s_sum[k][part] = t;
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    unsigned long long tot = 0;
+    for (int i = 0; i < 32; ++i) tot += s_sum[threadIdx.x][i];
+    const unsigned long long culled = (unsigned long long)n_inside - (unsigned long long)(*p.list_count);
+    if (threadIdx.x == 0 || threadIdx.x == 6 || (threadIdx.x == 3 && count_work)) tot += culled;
+    p.stats[threadIdx.x] = tot;
+  }
+}
+
+// ---- frame pipeline: k_cull -> k_compact -> k_render (persistent) -> k_stats_final -------------
+// Same-address atomics serialise at ~26 ns each on this part (measured: 10 k list appends cost
+// 267 us of a 325 us launch), so the compaction is atomic-free and the phase-B queue is sharded.
+constexpr int CULL_TPB = 64;          // tiles per k_cull / k_compact block: 16 rounds x 4 waves
+constexpr int N_SHARD = 64;           // phase-B queue shards, one 128-byte line each
+constexpr int SHARD_STRIDE = 32;      // uint32 words between shard heads
+
+// Phase A1 — cull.  One lane per pixel of an 8x8 tile.  A primary ray that misses the root box
+// (compute.wgsl:275 on node 0) can never hit anything: its pixel is final here ((0,0,0,1),
+// compute.wgsl:365-367).  The ballot of the remaining lanes is the tile's mask.
 __global__ __launch_bounds__(TBLK) void k_cull(const RtRenderParams p) {
-  const int lane = threadIdx.x & 63;
-  const uint32_t wave = blockIdx.x * (TBLK / 64) + (threadIdx.x >> 6), n_waves = gridDim.x * (TBLK / 64);
+  __shared__ uint32_t s_cnt[CULL_TPB];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float4 ra = reinterpret_cast<const float4*>(p.nodes)[0], rb = reinterpret_cast<const float4*>(p.nodes)[1];
-  Work W; W.box = W.tri = W.hit = W.drops = 0;
-  RayCount R; R.primary = R.shadow = R.bounce = 0;
-  uint32_t pixels = 0;
-  for (uint32_t tile = wave; tile < p.n_tiles; tile += n_waves) {
-    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
-    const uint32_t x = tx * 8u + (uint32_t)(lane & 7), lrow = ty * 8u + (uint32_t)(lane >> 3);
-    const uint32_t y = local_to_global_row(p, lrow);
-    const bool inside = (x < p.width && lrow < p.local_rows && y < p.height);
-    bool enters = false;
-    const uint32_t idx = lrow * p.width + x;
-    if (inside) {
-      const PrimaryRay pr = primary_ray(p.U, x, y, p.width, p.height);
-      float tn, tf; slab(pr.ro, pr.inv, xyz(ra), xyz(rb), tn, tf);
-      enters = box_hit(tn, tf, 1e20f);
-      if (!enters) {
-        if (p.rgba8) reinterpret_cast<uint32_t*>(p.rgba8)[idx] = 0xFF000000u;
-        if (p.hit_tri) p.hit_tri[idx] = 0xFFFFFFFFu;
-        if (p.hit_t) p.hit_t[idx] = 1e20f;
-        R.primary += 1; pixels += 1;
-        if (COUNT) W.box += 1;
+#pragma unroll 1
+  for (int r = 0; r < CULL_TPB / (TBLK / 64); ++r) {
+    const int k = r * (TBLK / 64) + w;                       // the 4 waves of a block work on 4 adjacent tiles
+    const uint32_t tile = blockIdx.x * CULL_TPB + (uint32_t)k;
+    unsigned long long m = 0ull;
+    if (tile < p.n_tiles) {
+      const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+      const uint32_t x = tx * 8u + (uint32_t)(lane & 7), lrow = ty * 8u + (uint32_t)(lane >> 3);
+      const uint32_t y = local_to_global_row(p, lrow);
+      bool enters = false;
+      if (x < p.width && lrow < p.local_rows && y < p.height) {
+        const uint32_t idx = lrow * p.width + x;
+        const PrimaryRay pr = primary_ray(p.U, x, y, p.width, p.height);
+        float tn, tf; slab(pr.ro, pr.inv, xyz(ra), xyz(rb), tn, tf);
+        enters = box_hit(tn, tf, 1e20f);
+        if (!enters) {                                        // ray / box-test / pixel counts: k_stats_final
+          if (p.rgba8) reinterpret_cast<uint32_t*>(p.rgba8)[idx] = 0xFF000000u;
+          if (p.hit_tri) p.hit_tri[idx] = 0xFFFFFFFFu;
+          if (p.hit_t) p.hit_t[idx] = 1e20f;
+        }
       }
+      m = __ballot(enters);
+      if (lane == 0) p.masks[tile] = m;
     }
-    const unsigned long long m = __ballot(enters);
-    if (m) {
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(p.list_count, (uint32_t)__popcll(m));
-      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-      const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-      if (enters) p.list[base + (uint32_t)__popcll(m & lt)] = idx;
-    }
+    if (lane == 0) s_cnt[k] = (uint32_t)__popcll(m);
   }
-  flush_stats<COUNT>(p, lane, R, W, pixels);
+  __syncthreads();
+  if (w == 0) {
+    const uint32_t tot = wave_sum_u32(s_cnt[lane]);
+    if (lane == 0) p.block_total[blockIdx.x] = tot;
+  }
 }
 
-// Phase B — persistent-thread traversal + shading over the compacted pixel list.  Each wave
-// owns chunk `wave` first, then pulls further 64-pixel chunks from a global atomic counter
-// (pre-set to the number of waves) until the list is drained.
+// Phase A2 — compact.  Block b owns the same 64 tiles as in k_cull; its list offset is the sum
+// of the totals of the blocks before it (a few KB read per block), the in-block offsets come
+// from a wave scan of the 64 tile popcounts.  Deterministic list order: tile-major.
+__global__ __launch_bounds__(TBLK) void k_compact(const RtRenderParams p) {
+  __shared__ uint32_t s_red[TBLK / 64];
+  __shared__ uint32_t s_pref[CULL_TPB];
+  __shared__ uint32_t s_tot;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t part = 0;
+  for (uint32_t i = threadIdx.x; i < blockIdx.x; i += TBLK) part += p.block_total[i];
+  part = wave_sum_u32(part);
+  if (lane == 0) s_red[w] = part;
+  if (w == 0) {
+    const uint32_t tile = blockIdx.x * CULL_TPB + (uint32_t)lane;
+    const uint32_t c = (tile < p.n_tiles) ? (uint32_t)__popcll(p.masks[tile]) : 0u;
+    uint32_t inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = (uint32_t)__shfl_up((int)inc, o);
+      if (lane >= o) inc += t;
+    }
+    s_pref[lane] = inc - c;
+    if (lane == 63) s_tot = inc;
+  }
+  __syncthreads();
+  uint32_t off = 0;
+#pragma unroll
+  for (int i = 0; i < TBLK / 64; ++i) off += s_red[i];
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *p.list_count = off + s_tot;
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll 1
+  for (int r = 0; r < CULL_TPB / (TBLK / 64); ++r) {
+    const int k = r * (TBLK / 64) + w;
+    const uint32_t tile = blockIdx.x * CULL_TPB + (uint32_t)k;
+    if (tile >= p.n_tiles) break;
+    const unsigned long long m = p.masks[tile];
+    if ((m >> lane) & 1ull) {
+      const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+      const uint32_t x = tx * 8u + (uint32_t)(lane & 7), lrow = ty * 8u + (uint32_t)(lane >> 3);
+      p.list[off + s_pref[k] + (uint32_t)__popcll(m & lt)] = lrow * p.width + x;
+    }
+  }
+}
+
+// Phase B — persistent-thread traversal + shading over the compacted pixel list (all 64 lanes
+// carry rays that enter the tree).  The 64-pixel chunks are split into N_SHARD contiguous
+// ranges, each with its own queue head on its own cache line.  A wave drains its home shard
+// (blocks with equal blockIdx % 8 share an XCD and get neighbouring shards = one image region,
+// for L2 locality only), then steals from whichever shard a cheap load scan shows non-empty.
 template <int LAYOUT, bool COUNT>
 __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -493,24 +568,38 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
   Work W; W.box = W.tri = W.hit = W.drops = 0;
   RayCount R; R.primary = R.shadow = R.bounce = 0;
   uint32_t pixels = 0;
-  const uint32_t n_list = *p.list_count;                 // written by k_cull (previous launch on this stream)
+  const uint32_t n_list = *p.list_count;                 // written by k_compact (previous launch on this stream)
   const uint32_t n_chunks = (n_list + 63u) / 64u;
-  uint32_t chunk = blockIdx.x * (TBLK / 64) + (threadIdx.x >> 6);
-  while (chunk < n_chunks) {
-    const uint32_t li = chunk * 64u + (uint32_t)lane;
-    if (li < n_list) {
-      const uint32_t idx = p.list[li];
-      const uint32_t x = idx % p.width, lrow = idx / p.width;
-      const uint32_t y = local_to_global_row(p, lrow);
-      const PixelOut o = shade_pixel<LAYOUT, COUNT>(S, sh, p.U, x, y, p.width, p.height, time_h, W, R);
-      if (p.rgba8) reinterpret_cast<uint32_t*>(p.rgba8)[idx] = o.rgba;
-      if (p.hit_tri) p.hit_tri[idx] = o.tri;
-      if (p.hit_t) p.hit_t[idx] = o.t;
-      pixels += 1;
+  // lane l looks after shard l: its chunk range [lo, hi)
+  const uint32_t my_lo = (uint32_t)(((unsigned long long)n_chunks * (uint32_t)lane) / N_SHARD);
+  const uint32_t my_hi = (uint32_t)(((unsigned long long)n_chunks * (uint32_t)(lane + 1)) / N_SHARD);
+  const uint32_t per_xcd = (gridDim.x + 7u) / 8u;
+  int shard = (int)((blockIdx.x & 7u) * (N_SHARD / 8) + ((blockIdx.x >> 3) * (N_SHARD / 8)) / per_xcd) & (N_SHARD - 1);
+  for (uint32_t scans = 0; scans <= 4u * N_SHARD; ++scans) {          // every wave reaches the exit: a scan that finds nothing
+    const uint32_t head = __hip_atomic_load(p.shard_heads + lane * SHARD_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long avail = __ballot(my_lo + head < my_hi);
+    if (!avail) break;
+    // first non-empty shard at or after `shard` (rotating)
+    const unsigned long long rot = (shard == 0) ? avail : ((avail >> shard) | (avail << (64 - shard)));
+    shard = (shard + (__ffsll((long long)rot) - 1)) & (N_SHARD - 1);
+    const uint32_t lo = (uint32_t)__shfl((int)my_lo, shard), hi = (uint32_t)__shfl((int)my_hi, shard);
+    for (;;) {
+      uint32_t h = 0;
+      if (lane == 0) h = atomicAdd(p.shard_heads + shard * SHARD_STRIDE, 1u);
+      const uint32_t chunk = lo + (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
+      if (chunk >= hi) break;
+      const uint32_t li = chunk * 64u + (uint32_t)lane;
+      if (li < n_list) {
+        const uint32_t idx = p.list[li];
+        const uint32_t x = idx % p.width, lrow = idx / p.width;
+        const uint32_t y = local_to_global_row(p, lrow);
+        const PixelOut o = shade_pixel<LAYOUT, COUNT>(S, sh, p.U, x, y, p.width, p.height, time_h, W, R);
+        if (p.rgba8) reinterpret_cast<uint32_t*>(p.rgba8)[idx] = o.rgba;
+        if (p.hit_tri) p.hit_tri[idx] = o.tri;
+        if (p.hit_t) p.hit_t[idx] = o.t;
+        pixels += 1;
+      }
     }
-    uint32_t next = 0;
-    if (lane == 0) next = atomicAdd(p.tile_counter, 1u);
-    chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
   }
   flush_stats<COUNT>(p, lane, R, W, pixels);
 }
@@ -531,16 +620,14 @@ __global__ __launch_bounds__(TBLK) void k_deinterleave(const T* __restrict__ pac
 }  // namespace
 
 uint32_t rt_render_grid(int n_cu) { return (uint32_t)n_cu * 4u; }   // ~4 resident 256-thread blocks per CU (128 VGPRs)
+uint32_t rt_cull_blocks(uint32_t n_tiles) { return (n_tiles + CULL_TPB - 1) / CULL_TPB; }
+uint32_t rt_shard_words() { return N_SHARD * SHARD_STRIDE; }
 
+// The caller zeroes shard_heads; masks / block_total / list / list_count are fully rewritten.
 void rt_launch_render(const RtRenderParams& p, int layout, bool count_work, int n_cu, hipStream_t s) {
-  const dim3 b(TBLK);
-  // phase A: cull + compact (tile_counter / list_count are reset by the caller)
-  uint32_t cull_blocks = (p.n_tiles + (TBLK / 64) - 1) / (TBLK / 64);
-  if (cull_blocks > (uint32_t)n_cu * 8u) cull_blocks = (uint32_t)n_cu * 8u;
-  if (cull_blocks < 1) cull_blocks = 1;
-  if (count_work) hipLaunchKernelGGL((k_cull<true>), dim3(cull_blocks), b, 0, s, p);
-  else hipLaunchKernelGGL((k_cull<false>), dim3(cull_blocks), b, 0, s, p);
-  // phase B: persistent traversal over the compacted list
+  const dim3 b(TBLK), gc(rt_cull_blocks(p.n_tiles));
+  hipLaunchKernelGGL(k_cull, gc, b, 0, s, p);
+  hipLaunchKernelGGL(k_compact, gc, b, 0, s, p);
   const dim3 g(rt_render_grid(n_cu));
   const size_t lds = (size_t)p.max_stack * TBLK * (sizeof(uint32_t) + sizeof(float));
   if (layout == RT_LAYOUT_WIDE64) {
@@ -550,6 +637,7 @@ void rt_launch_render(const RtRenderParams& p, int layout, bool count_work, int 
     if (count_work) hipLaunchKernelGGL((k_render<RT_LAYOUT_AOS32, true>), g, b, lds, s, p);
     else hipLaunchKernelGGL((k_render<RT_LAYOUT_AOS32, false>), g, b, lds, s, p);
   }
+  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(256), 0, s, p, g.x, p.local_rows * p.width, count_work ? 1 : 0);
 }
 
 void rt_launch_deinterleave(const void* packed, void* image, uint32_t width, uint32_t height, uint32_t elem_bytes,
