@@ -586,6 +586,7 @@ inline V3 mat_mul3(const float* m, V3 v) {
 }
 
 struct Pixel { float r, g, b, a; uint32_t tri; float t; };
+thread_local uint32_t* g_work_img = nullptr;   // optional per-pixel box-test count (analysis only)
 
 // web/compute.wgsl:349-410
 Pixel compute_lighting(const Scene& S, const float* U, V3 ro_w, V3 rd_w, uint32_t pixelIndex, float time, Counters& C) {
@@ -650,8 +651,10 @@ void render_pixel(const Scene& S, const float* U, uint32_t gx, uint32_t gy, uint
   float py = fminf(fmaxf(uvy * (float)h, 0.0f), (float)(h - 1));
   uint32_t ix = sat_u32(px), iy = sat_u32(py);
   uint32_t pixelIndex = iy * w + ix;
+  const uint64_t box0 = C.box;
   Pixel p = compute_lighting(S, U, ro, rd, pixelIndex, time_h, C);
   size_t o = (size_t)gy * w + gx;
+  if (g_work_img) g_work_img[o] = (uint32_t)(C.box - box0);
   if (rgba8) { rgba8[4 * o + 0] = unorm8(p.r); rgba8[4 * o + 1] = unorm8(p.g); rgba8[4 * o + 2] = unorm8(p.b); rgba8[4 * o + 3] = unorm8(p.a); }
   if (hit_tri) hit_tri[o] = p.tri;
   if (hit_t) hit_t[o] = p.t;
@@ -659,6 +662,9 @@ void render_pixel(const Scene& S, const float* U, uint32_t gx, uint32_t gy, uint
 }
 
 }  // namespace
+
+static uint32_t* g_work_request = nullptr;
+extern "C" void orc_set_work_image(uint32_t* img) { g_work_request = img; }   // box tests per pixel of the next orc_render calls
 
 extern "C" int orc_render(const float* nodes, uint32_t n_nodes, const float* tri_pos, const float* tri_nor,
                           uint32_t n_tri, const float U[44], const orc_render_opts* o,
@@ -675,6 +681,7 @@ extern "C" int orc_render(const float* nodes, uint32_t n_nodes, const float* tri
   auto t0 = std::chrono::steady_clock::now();
   auto work = [&](int tid) {
     Counters& C = cs[tid];
+    g_work_img = g_work_request;
     int k = 0;
     for (int y = r0; y < r1; y += rs, ++k) {
       if (k % nthr != tid) continue;

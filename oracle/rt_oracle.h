@@ -100,6 +100,9 @@ int orc_render(const float* nodes, uint32_t n_nodes, const float* tri_pos, const
                uint32_t n_tri, const float uniforms[44], const orc_render_opts* opts,
                uint8_t* rgba8, uint32_t* hit_tri, float* hit_t, orc_render_stats* stats);
 
+/* analysis aid: when non-NULL, later orc_render calls also write box tests per pixel (w*h) */
+void orc_set_work_image(uint32_t* img);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,7 +3,9 @@
 // point needs a usable HIP device.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -484,6 +486,7 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
   HIPCHK(ctx->r_tile_counter.ensure(rt_shard_words() + 32 + cull_blocks));
   HIPCHK(ctx->r_stats.ensure(8 + (size_t)rt_render_grid(ctx->n_cu) * 8 + p.n_tiles));
   HIPCHK(ctx->r_list.ensure((size_t)p.local_rows * p.width));
+  p.shard_stride = rt_shard_stride();
   p.shard_heads = ctx->r_tile_counter.p; p.list_count = ctx->r_tile_counter.p + rt_shard_words();
   p.block_total = ctx->r_tile_counter.p + rt_shard_words() + 32;
   p.list = ctx->r_list.p;

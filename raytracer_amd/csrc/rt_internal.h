@@ -52,6 +52,7 @@ struct RtRenderParams {
   uint32_t* hit_tri;
   float*    hit_t;
   uint32_t* shard_heads;           // [rt_shard_words()] phase-B queue heads, one per 128-byte line; zeroed before launch
+  uint32_t shard_stride;           // words between shard heads
   unsigned long long* masks;       // [n_tiles] per-tile ballot of pixels whose primary ray enters the root box
   uint32_t* block_total;           // [rt_cull_blocks(n_tiles)]
   uint32_t* list;                  // [local_rows*width] compacted pixel ids (phase A -> phase B)
@@ -92,6 +93,7 @@ void rt_launch_pack_impl(const RtBvhDev& bvh, uint32_t* d_root_ref, uint32_t* d_
 uint32_t rt_render_grid(int n_cu);   // blocks of the persistent phase-B grid
 uint32_t rt_cull_blocks(uint32_t n_tiles);
 uint32_t rt_shard_words();
+uint32_t rt_shard_stride();
 void rt_launch_render(const RtRenderParams& p, int layout, bool count_work, int n_cu, hipStream_t s);
 void rt_launch_deinterleave(const void* packed, void* image, uint32_t width, uint32_t height, uint32_t elem_bytes,
                             int stripe_rows, int world, uint32_t rows_per_rank, hipStream_t s);

@@ -457,7 +457,7 @@ __global__ void k_stats_final(const RtRenderParams p, uint32_t n_blocks, uint32_
 // 267 us of a 325 us launch), so the compaction is atomic-free and the phase-B queue is sharded.
 constexpr int CULL_TPB = 64;          // tiles per k_cull / k_compact block: 16 rounds x 4 waves
 constexpr int N_SHARD = 64;           // phase-B queue shards, one 128-byte line each
-constexpr int SHARD_STRIDE = 32;      // uint32 words between shard heads
+static int shard_stride_words() { return 32; }   // uint32 words between shard heads: one 128-byte line each
 
 // Phase A1 — cull.  One lane per pixel of an 8x8 tile.  A primary ray that misses the root box
 // (compute.wgsl:275 on node 0) can never hit anything: its pixel is final here ((0,0,0,1),
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
   const uint32_t per_xcd = (gridDim.x + 7u) / 8u;
   int shard = (int)((blockIdx.x & 7u) * (N_SHARD / 8) + ((blockIdx.x >> 3) * (N_SHARD / 8)) / per_xcd) & (N_SHARD - 1);
   for (uint32_t scans = 0; scans <= 4u * N_SHARD; ++scans) {          // every wave reaches the exit: a scan that finds nothing
-    const uint32_t head = __hip_atomic_load(p.shard_heads + lane * SHARD_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t head = __hip_atomic_load(p.shard_heads + (size_t)lane * p.shard_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long avail = __ballot(my_lo + head < my_hi);
     if (!avail) break;
     // first non-empty shard at or after `shard` (rotating)
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
     const uint32_t lo = (uint32_t)__shfl((int)my_lo, shard), hi = (uint32_t)__shfl((int)my_hi, shard);
     for (;;) {
       uint32_t h = 0;
-      if (lane == 0) h = atomicAdd(p.shard_heads + shard * SHARD_STRIDE, 1u);
+      if (lane == 0) h = atomicAdd(p.shard_heads + (size_t)shard * p.shard_stride, 1u);
       const uint32_t chunk = lo + (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
       if (chunk >= hi) break;
       const uint32_t li = chunk * 64u + (uint32_t)lane;
@@ -619,16 +619,30 @@ __global__ __launch_bounds__(TBLK) void k_deinterleave(const T* __restrict__ pac
 
 }  // namespace
 
-uint32_t rt_render_grid(int n_cu) { return (uint32_t)n_cu * 4u; }   // ~4 resident 256-thread blocks per CU (128 VGPRs)
+// Persistent grid of phase B: what is actually resident (occupancy query), so that no block starts
+// late behind another one (measured: with a 4-blocks/CU grid and 3 resident, a quarter of the
+// waves started 400 us into a 650 us launch).
+uint32_t rt_render_grid(int n_cu) { return (uint32_t)n_cu * 4u; }   // upper bound (sizes the per-block stats slots)
+static uint32_t resident_grid(int n_cu, int max_stack) {
+  static int per_cu[33] = {0};
+  if (per_cu[max_stack] == 0) {
+    int nb = 0;
+    const size_t lds = (size_t)max_stack * TBLK * 8;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_render<RT_LAYOUT_WIDE64, true>), TBLK, lds) != hipSuccess || nb < 1) nb = 2;
+    per_cu[max_stack] = nb > 4 ? 4 : nb;
+  }
+  return (uint32_t)n_cu * (uint32_t)per_cu[max_stack];
+}
 uint32_t rt_cull_blocks(uint32_t n_tiles) { return (n_tiles + CULL_TPB - 1) / CULL_TPB; }
-uint32_t rt_shard_words() { return N_SHARD * SHARD_STRIDE; }
+uint32_t rt_shard_words() { return N_SHARD * (uint32_t)shard_stride_words(); }
+uint32_t rt_shard_stride() { return (uint32_t)shard_stride_words(); }
 
 // The caller zeroes shard_heads; masks / block_total / list / list_count are fully rewritten.
 void rt_launch_render(const RtRenderParams& p, int layout, bool count_work, int n_cu, hipStream_t s) {
   const dim3 b(TBLK), gc(rt_cull_blocks(p.n_tiles));
   hipLaunchKernelGGL(k_cull, gc, b, 0, s, p);
   hipLaunchKernelGGL(k_compact, gc, b, 0, s, p);
-  const dim3 g(rt_render_grid(n_cu));
+  const dim3 g(resident_grid(n_cu, p.max_stack));
   const size_t lds = (size_t)p.max_stack * TBLK * (sizeof(uint32_t) + sizeof(float));
   if (layout == RT_LAYOUT_WIDE64) {
     if (count_work) hipLaunchKernelGGL((k_render<RT_LAYOUT_WIDE64, true>), g, b, lds, s, p);
