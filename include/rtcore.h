@@ -202,8 +202,8 @@ typedef struct rt_bvh_view {
   uint32_t n_nodes, n_tri;
 } rt_bvh_view;
 int rt_bvh_view_get(rt_ctx* ctx, rt_bvh_view* out);
-/* Copy the three flat buffers into caller-owned device memory of the same sizes (e.g. torch
- * tensors that RCCL then broadcasts). Synchronous on the context stream. */
+/* Copy the three flat buffers into caller-owned device memory of the same sizes (e.g. buffers
+ * that RCCL then broadcasts). Synchronous on the context stream. */
 int rt_bvh_export_device(rt_ctx* ctx, const rt_bvh_view* dst);
 /* Adopt caller-owned device buffers (filled by a broadcast) as this context's BVH and derive
  * the traversal layout from them.  The caller keeps the three buffers alive. */

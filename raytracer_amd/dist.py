@@ -43,6 +43,8 @@ class GpuBackend:
         return st
 
     def deinterleave(self, gathered, image, width, height, world, rpr):
+        # the collective ran on torch's streams, the de-interleave kernel runs on the context's stream
+        torch.cuda.current_stream(self.device).synchronize()
         self.ctx.deinterleave_device(gathered.data_ptr(), image.data_ptr(), width, height, 4, STRIPE_ROWS, world, rpr)
         self.ctx.synchronize()
 
@@ -62,7 +64,8 @@ def replicate_bvh(ctx, rank, world, device):
         ctx.export_bvh_device(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), N, T)
     for b in bufs:                      # three large broadcasts (32 B x N, 48 B x T, 48 B x T)
         dist.broadcast(b, 0)
-    torch.cuda.synchronize(device)
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
     if rank != 0:
         ctx.adopt_bvh_device(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), N, T)
     return bufs

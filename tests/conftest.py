@@ -44,13 +44,13 @@ def plane_mesh(rt, plane_obj_path):
     return rt.normalize_mesh(rt.load_obj(plane_obj_path))
 
 
-def random_soup(n_tri, seed, quantum=None, scale=1.0):
+def random_soup(n_tri, seed, quantum=None, scale=1.0, size=0.02):
     """Seeded triangle soup; `quantum` snaps centroids onto a coarse grid to force duplicate Morton codes."""
     rng = np.random.default_rng(seed)
     c = rng.random((n_tri, 1, 3))
     if quantum:
         c = np.floor(c * quantum) / quantum
-    p = (c + (rng.random((n_tri, 3, 3)) - 0.5) * 0.02) * scale
+    p = (c + (rng.random((n_tri, 3, 3)) - 0.5) * size) * scale
     pos = p.reshape(-1, 3).astype(np.float32)
     nor = rng.standard_normal((n_tri * 3, 3)).astype(np.float32)
     nor /= np.linalg.norm(nor, axis=1, keepdims=True)

@@ -1,0 +1,111 @@
+"""CPU-only, world_size 2 over gloo: the multi-GPU host logic of raytracer_amd/dist.py (BVH
+replication + stripe sharding + packed all-gather + de-interleave) with the ORACLE standing in
+for the GPU backend.  The gathered frame must equal the unsharded oracle frame on every rank."""
+import ctypes
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleBackend:
+    """Same interface as dist.GpuBackend, rendering this rank's stripes with the CPU oracle."""
+
+    def __init__(self, oracle, bvh):
+        self.o, self.bvh = oracle, bvh
+
+    def alloc(self, rows, width):
+        return torch.zeros((rows, width), dtype=torch.int32)
+
+    def render_packed(self, U, opts, packed):
+        from raytracer_amd import dist as rdist
+        h = int(U[37])
+        ys = rdist.stripe_rows_of(h, opts.stripe_rank, opts.stripe_world) if opts.stripe_rows else np.arange(h)
+        out, st = self.o.render(self.bvh["nodes"], self.bvh["tri_pos"], self.bvh["tri_nor"], U, mode=opts.mode,
+                                gi_samples=opts.gi_samples, want=("rgba8",))
+        img = out["rgba8"].view(np.int32)[:, :, 0]
+        packed[:len(ys)] = torch.from_numpy(img[ys].copy())
+        return st
+
+    def deinterleave(self, gathered, image, width, height, world, rpr):
+        from raytracer_amd import dist as rdist
+        g = gathered.view(world, rpr, width)
+        for r in range(world):
+            ys = rdist.stripe_rows_of(height, r, world)
+            image[torch.from_numpy(ys)] = g[r, :len(ys)]
+
+
+class FakeCtx:
+    """counts / export / adopt of the C ABI, on host memory."""
+
+    def __init__(self, bvh=None):
+        self.bvh, self.adopted = bvh, None
+
+    def counts(self):
+        return self.bvh["tri_pos"].shape[0], self.bvh["nodes"].shape[0]
+
+    def export_bvh_device(self, pn, pp, pq, N, T):
+        for ptr, arr in ((pn, self.bvh["nodes"]), (pp, self.bvh["tri_pos"]), (pq, self.bvh["tri_nor"])):
+            a = np.ascontiguousarray(arr, np.float32)
+            ctypes.memmove(ptr, a.ctypes.data, a.nbytes)
+
+    def adopt_bvh_device(self, pn, pp, pq, N, T):
+        rd = lambda p, n: np.frombuffer((ctypes.c_float * n).from_address(p), np.float32).copy()
+        self.adopted = dict(nodes=rd(pn, 8 * N).reshape(N, 8), tri_pos=rd(pp, 12 * T).reshape(T, 3, 4), tri_nor=rd(pq, 12 * T).reshape(T, 3, 4))
+
+
+def _worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import raytracer_amd as rt
+        from oracle import binding as oracle
+        from raytracer_amd import dist as rdist
+        mesh = rt.generate_test_scene()
+        bvh = oracle.build_lbvh(mesh.positions, mesh.normals, mesh.vert_idx, mesh.norm_idx) if rank == 0 else None
+        ctx = FakeCtx(bvh)
+        keep = rdist.replicate_bvh(ctx, rank, world, "cpu")           # BVH built on rank 0 only, broadcast to the rest
+        mine = bvh if rank == 0 else ctx.adopted
+        assert mine is not None and len(keep) == 3
+        w, h = 50, 70                                                   # not multiples of the 16-row stripes
+        U = rt.make_uniforms(w, h, cam_pos=(0.0, 0.0, 3.0))
+        U[20:36] = np.eye(4, dtype=np.float32).reshape(-1)
+        frame = rdist.ShardedFrame(OracleBackend(oracle, mine), w, h, rank, world, rt.render_opts(mode=rt.MODE_SHADOW))
+        assert frame.rpr == rt.packed_rows(h, 16, 0, world)
+        frame.step(U)
+        ref, _ = oracle.render(mine["nodes"], mine["tri_pos"], mine["tri_nor"], U, mode=1, want=("rgba8",))
+        ok = np.array_equal(frame.image.numpy(), ref["rgba8"].view(np.int32)[:, :, 0]) and (ref["rgba8"][..., 0] > 0).any()
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gloo_sharded_frame():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctxmp = mp.get_context("spawn")
+    q = ctxmp.Queue()
+    procs = [ctxmp.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
+
+
+def test_stripe_ownership_partition():
+    from raytracer_amd import dist as rdist
+    for h in (1, 16, 33, 150, 2160):
+        for world in (1, 2, 4, 8):
+            ys = np.concatenate([rdist.stripe_rows_of(h, r, world) for r in range(world)])
+            assert np.array_equal(np.sort(ys), np.arange(h))
+            assert rdist.rows_per_rank(h, world) >= max(len(rdist.stripe_rows_of(h, r, world)) for r in range(world))
