@@ -399,6 +399,7 @@ struct Scene {
   const float* tri_pos; const float* tri_nor; uint32_t n_tri;
   int max_stack, gi_samples, gi_bounces, soft_samples, mode;
 };
+uint32_t* g_visit_counts = nullptr;        // analysis only, single-threaded use: internal steps per node
 struct Counters {
   uint64_t rays_primary = 0, rays_shadow = 0, rays_bounce = 0, box = 0, tri = 0, hitupd = 0, pixels = 0, drops = 0;
 };
@@ -469,6 +470,7 @@ Hit traverse(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Counters& C) {
         if (sp > 0) { sp -= 1; cur = stack[sp]; } else break;
       } else {
         int c0 = node.child0, c1 = node.child1;
+        if (g_visit_counts) g_visit_counts[cur] += 1;
         CachedNode n0 = fetch_node(S, c0), n1 = fetch_node(S, c1);
         float b0x, b0y, b1x, b1y;
         aabb(ro, inv, n0.mn, n0.mx, b0x, b0y);
@@ -664,7 +666,8 @@ void render_pixel(const Scene& S, const float* U, uint32_t gx, uint32_t gy, uint
 }  // namespace
 
 static uint32_t* g_work_request = nullptr;
-extern "C" void orc_set_work_image(uint32_t* img) { g_work_request = img; }   // box tests per pixel of the next orc_render calls
+extern "C" void orc_set_work_image(uint32_t* img) { g_work_request = img; }
+extern "C" void orc_set_visit_counts(uint32_t* per_node) { g_visit_counts = per_node; }   // closest-hit internal steps per node (run with n_threads = 1)   // box tests per pixel of the next orc_render calls
 
 extern "C" int orc_render(const float* nodes, uint32_t n_nodes, const float* tri_pos, const float* tri_nor,
                           uint32_t n_tri, const float U[44], const orc_render_opts* o,

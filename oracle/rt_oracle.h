@@ -102,6 +102,8 @@ int orc_render(const float* nodes, uint32_t n_nodes, const float* tri_pos, const
 
 /* analysis aid: when non-NULL, later orc_render calls also write box tests per pixel (w*h) */
 void orc_set_work_image(uint32_t* img);
+/* analysis aid (single-threaded renders only): counts closest-hit internal steps per node */
+void orc_set_visit_counts(uint32_t* per_node);
 
 #ifdef __cplusplus
 }
