@@ -82,12 +82,22 @@ RT_DEV Hit closest_wide(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Wor
     }
     return REF_DONE;
   };
-  uint32_t budget = S.step_budget;
+  // One loop, one memory round trip per iteration: a lane at an internal node fetches its 64-byte
+  // record, a lane at a leaf fetches its triangle, from ONE set of loads.  (The descend-loop /
+  // leaf-loop form made lanes that reached a leaf wait for the slowest descent and paid two
+  // dependent round trips per visited leaf.)
+  uint32_t budget = S.step_budget, leaf_j = 0;
   while (cur != REF_DONE) {
-    while ((int)cur >= 0) {                            // internal: both children from one 64 B record
-      if (--budget == 0) { cur = REF_DONE; sp = 0; break; }
-      const float4* n = S.wide + 4 * (size_t)cur;
-      const float4 a = n[0], b = n[1], c = n[2], d = n[3];
+    if (--budget == 0) break;
+    const bool is_leaf = (int)cur < 0;
+    const uint32_t body = cur & 0x7FFFFFFFu;
+    const uint32_t start = (S.leaf_shift >= 31) ? body : (body & ((1u << S.leaf_shift) - 1u));
+    const uint32_t count = (S.leaf_shift >= 31) ? 1u : ((body >> S.leaf_shift) + 1u);
+    const uint32_t ti = start + leaf_j;
+    const float4* ptr = is_leaf ? (S.tri_pre + 3 * (size_t)ti) : (S.wide + 4 * (size_t)cur);
+    const float4 a = ptr[0], b = ptr[1], c = ptr[2];
+    if (!is_leaf) {                                      // internal: both children from one 64 B record
+      const float4 d = ptr[3];
       float t0n, t0f, t1n, t1f;
       slab(ro, inv, xyz(a), xyz(b), t0n, t0f);
       slab(ro, inv, xyz(c), xyz(d), t1n, t1f);
@@ -105,21 +115,16 @@ RT_DEV Hit closest_wide(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Wor
       } else if (hit0) cur = r0;
       else if (hit1) cur = r1;
       else cur = pop();
-    }
-    if (cur == REF_DONE) break;
-    const uint32_t body = cur & 0x7FFFFFFFu;
-    const uint32_t start = (S.leaf_shift >= 31) ? body : (body & ((1u << S.leaf_shift) - 1u));
-    const uint32_t count = (S.leaf_shift >= 31) ? 1u : ((body >> S.leaf_shift) + 1u);
-    for (uint32_t j = 0; j < count; ++j) {
-      const uint32_t ti = start + j;
-      const float4 q0 = S.tri_pre[3 * (size_t)ti + 0], q1 = S.tri_pre[3 * (size_t)ti + 1], q2 = S.tri_pre[3 * (size_t)ti + 2];
+    } else {
       if (COUNT) W.tri += 1;
-      if (dot3(v3(q0.w, q1.w, q2.w), rd) > 0.0f) continue;        // back-face pre-cull, compute.wgsl:282
-      float t, u, v;
-      const bool hit = moller_trumbore(ro, rd, xyz(q0), xyz(q1), xyz(q2), t, u, v);
-      if (hit && t < bestT) { bestT = t; bestTri = ti; bu = u; bv = v; if (COUNT) W.hit += 1; }
+      if (!(dot3(v3(a.w, b.w, c.w), rd) > 0.0f)) {      // back-face pre-cull, compute.wgsl:282
+        float t, u, v;
+        const bool hit = moller_trumbore(ro, rd, xyz(a), xyz(b), xyz(c), t, u, v);
+        if (hit && t < bestT) { bestT = t; bestTri = ti; bu = u; bv = v; if (COUNT) W.hit += 1; }
+      }
+      leaf_j += 1;
+      if (leaf_j >= count) { leaf_j = 0; cur = pop(); }
     }
-    cur = pop();
   }
   Hit h; h.t = bestT; h.tri = bestTri; h.u = bu; h.v = bv;
   return h;
