@@ -116,10 +116,10 @@ def main():
     my_bytes = 32 * cst["box_tests"] + 48 * cst["tri_tests"] + 48 * cst["hit_updates"] + 4 * cst["pixels"]
 
     for _ in range(args.warmup):
-        frame.step(U)
+        frame.step(U, want_stats=False)
 
     def fence():
-        ctx.synchronize()
+        frame.finish()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -127,13 +127,14 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    kernel_ms = 0.0
+    # frames are queued asynchronously, as a frame loop would; hipEvents recorded on the context's own stream
+    # around every frame's kernels (rt_profile_begin/end) give the per-kernel durations of exactly these K steps
+    ctx.profile_begin()
     for _ in range(args.steps):
-        st = frame.step(U)
-        kernel_ms += st["ms_kernel"]          # hipEvent pair around the traversal kernel on the context's stream
+        frame.step(U, want_stats=False)
     fence()
     elapsed = time.perf_counter() - t0
-    kernel_ms /= max(args.steps, 1)
+    kernel_ms, trav_ms, _n = ctx.profile_end()   # frame pipeline (cull, compact, traversal, stats) / k_render alone
 
     tot = torch.tensor([float(my_rays), float(my_bytes), elapsed, kernel_ms], dtype=torch.float64, device=device)
     if world > 1:
@@ -149,7 +150,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = total_rays * args.steps / elapsed / 1e6
         # roofline of the dominant kernel (traversal): this rank's algorithmic bytes / its average launch duration
-        achieved = my_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        achieved = my_bytes / (trav_ms * 1e-3) / 1e9 if trav_ms > 0 else 0.0
         out = {
             "metric": "Mrays/s primary+shadow, dragon.obj 4K" if args.mode == "shadow" else f"Mrays/s {args.mode}",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -161,10 +162,10 @@ def main():
             "lbvh_build_ms": {k: round(float(v), 4) for k, v in build.items() if k.startswith("ms_")},
             "lbvh_build_roofline_frac": round(build["algorithmic_bytes"] / (build["ms_total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
             "bvh_broadcast_ms": round(bcast_ms, 3),
-            "kernel_ms": round(kernel_ms, 4), "kernel_ms_max_rank": round(kernel_max, 4),
+            "frame_kernels_ms": round(kernel_ms, 4), "frame_kernels_ms_max_rank": round(kernel_max, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "kernel": "k_render", "algorithmic_bytes_per_launch": int(my_bytes)},
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(args, world),
+                         "kernel": "k_render", "kernel_ms": round(trav_ms, 4), "algorithmic_bytes_per_launch": int(my_bytes)},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, mesh, U, mode)
@@ -173,6 +174,22 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+
+
+def pmc_traffic(args, world):
+    """HBM bytes per k_render launch from the PMC passes (scripts/pmc_passes.sh -> scripts/pmc_summary.py,
+    2 x FETCH_SIZE + WRITE_SIZE per MI355X_MICROARCH.md), committed as profiles/traffic.json.  The counters
+    need rocprofv3 runs of their own, so the figure is read back from the last committed collection and is
+    only reported when that collection was made on this exact workload; otherwise null."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        t = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    w = t.get("workload", {})
+    same = (world == 1 and w.get("scene") == args.scene and w.get("width") == args.width and w.get("height") == args.height
+            and w.get("mode") == args.mode and w.get("layout") == args.layout and (args.mode != "pt" or w.get("spp") == args.spp))
+    return t.get("k_render_hbm_bytes_per_launch") if same else None
 
 
 def cpu_baseline(args, mesh, U, mode):
@@ -188,12 +205,19 @@ def cpu_baseline(args, mesh, U, mode):
     per_row = max(st["seconds"] / max(1, len(range(0, H, max(1, H // 8)))), 1e-6)
     n_rows = int(min(H, max(8, args.cpu_seconds / per_row)))
     step = max(1, H // n_rows)
-    _, st = oracle.render(b["nodes"], b["tri_pos"], b["tri_nor"], U, mode=mode, gi_samples=args.spp, rows=(0, H, step),
-                          n_threads=cores, want=())
-    rays = st["rays_primary"] + st["rays_shadow"] + st["rays_bounce"]
-    return {"value": round(rays / st["seconds"] / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"rows 0..{H} step {step} of the same {args.width}x{H} frame ({len(range(0, H, step))} rows, "
-                      f"{rays} rays, {st['seconds']:.2f} s)",
+    # repeat the sample until ~cpu_seconds of CPU work (wall x threads) has been spent, at least twice
+    rays = 0
+    secs = 0.0
+    reps = 0
+    while reps < 2 or (secs * cores < args.cpu_seconds and reps < 64):
+        _, st = oracle.render(b["nodes"], b["tri_pos"], b["tri_nor"], U, mode=mode, gi_samples=args.spp, rows=(0, H, step),
+                              n_threads=cores, want=())
+        rays += st["rays_primary"] + st["rays_shadow"] + st["rays_bounce"]
+        secs += st["seconds"]
+        reps += 1
+    return {"value": round(rays / secs / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"rows 0..{H} step {step} of the same {args.width}x{H} frame ({len(range(0, H, step))} rows) x {reps} "
+                      f"repeats: {rays} rays in {secs:.2f} s wall on {cores} threads ({secs * cores:.1f} s of CPU work)",
             "lbvh_build_ms": round(b["seconds"] * 1e3, 2), "lbvh_build_cores": 1}
 
 

@@ -169,7 +169,8 @@ typedef struct rt_render_stats {
   uint64_t box_tests, tri_tests, hit_updates;   /* only with RT_FLAG_COUNT_WORK */
   uint64_t pixels;
   uint64_t stack_drops;                          /* only with RT_FLAG_COUNT_WORK */
-  float    ms_kernel;                            /* hipEvent time of the traversal kernel */
+  float    ms_kernel;                            /* hipEvent time of the frame pipeline (cull + compact + traversal + stats) */
+  float    ms_traverse;                          /* hipEvent time of the traversal kernel (k_render) alone */
 } rt_render_stats;
 
 /* Replaces queue.writeBuffer(uniformBuf) + dispatchWorkgroups(ceil(w/16), ceil(h/16)) of
@@ -208,6 +209,14 @@ int rt_bvh_export_device(rt_ctx* ctx, const rt_bvh_view* dst);
 /* Adopt caller-owned device buffers (filled by a broadcast) as this context's BVH and derive
  * the traversal layout from them.  The caller keeps the three buffers alive. */
 int rt_bvh_adopt_device(rt_ctx* ctx, const rt_bvh_view* view);
+
+/* Instrumentation for asynchronous frame loops (the counterpart of the reference's FPS counter,
+ * script.js:951-957, at kernel resolution): between begin and end every rt_render_device records
+ * hipEvents around the frame's kernels without synchronising; end synchronises the stream and
+ * returns the averages over the (last <= 256) frames: ms_frame = cull + compact + traversal + stats,
+ * ms_traverse = the traversal kernel alone. */
+int rt_profile_begin(rt_ctx* ctx);
+int rt_profile_end(rt_ctx* ctx, float* ms_frame_avg, float* ms_traverse_avg, uint32_t* n_frames);
 
 int rt_synchronize(rt_ctx* ctx);
 /* The hipStream_t the context launches on (as void*), so hosts can order their own work. */

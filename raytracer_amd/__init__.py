@@ -250,3 +250,12 @@ class Context:
 
     def stream(self):
         return _L.rt_stream(self._h)
+
+    def profile_begin(self):
+        self._chk(_L.rt_profile_begin(self._h))
+
+    def profile_end(self):
+        """-> (ms_frame_avg, ms_traverse_avg, n_frames) over the frames launched since profile_begin."""
+        a, b, n = C.c_float(), C.c_float(), C.c_uint32()
+        self._chk(_L.rt_profile_end(self._h, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value

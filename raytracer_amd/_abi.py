@@ -23,6 +23,7 @@ SYMBOLS = [
     "rt_get_nodes", "rt_get_triangles", "rt_set_bvh", "rt_save_bvh", "rt_load_bvh",
     "rt_render_opts_default", "rt_render", "rt_render_device", "rt_packed_rows", "rt_deinterleave_device",
     "rt_bvh_view_get", "rt_bvh_export_device", "rt_bvh_adopt_device", "rt_synchronize", "rt_stream",
+    "rt_profile_begin", "rt_profile_end",
 ]
 
 
@@ -61,7 +62,7 @@ class RenderOpts(C.Structure):
 
 class RenderStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays_primary", "rays_shadow", "rays_bounce", "box_tests", "tri_tests",
-                                          "hit_updates", "pixels", "stack_drops")] + [("ms_kernel", C.c_float)]
+                                          "hit_updates", "pixels", "stack_drops")] + [("ms_kernel", C.c_float), ("ms_traverse", C.c_float)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -72,10 +73,31 @@ class BvhView(C.Structure):
                 ("d_tri_nor", C.c_void_p), ("tri_nor_bytes", C.c_uint64), ("n_nodes", C.c_uint32), ("n_tri", C.c_uint32)]
 
 
+def _share_hip_runtime_with_torch():
+    """One process, one HIP runtime.  librtcore.so needs libamdhip64 (the system one under /opt/rocm by
+    default); a PyTorch-ROCm wheel bundles its own copy, and whichever copy is loaded second finds no GPU
+    ("No HIP GPUs are available").  dist.py and bench.py use torch for device buffers and RCCL next to this
+    library, so when a torch wheel with a bundled runtime is installed, that copy is loaded first and
+    librtcore.so binds to it (same SONAME).  RTCORE_HIP_RUNTIME=system skips this (torch-free hosts)."""
+    if os.environ.get("RTCORE_HIP_RUNTIME", "") == "system":
+        return
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `make lib` (or __graft_entry__.build()). "
                           "raytracer_amd has no CPU fallback.")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     vp, u32, i32, f32p = C.c_void_p, C.c_uint32, C.c_int32, C.POINTER(C.c_float)
     u32p, cp = C.POINTER(C.c_uint32), C.c_char_p
@@ -113,6 +135,8 @@ def load():
         "rt_bvh_adopt_device": (C.c_int, [vp, C.POINTER(BvhView)]),
         "rt_synchronize": (C.c_int, [vp]),
         "rt_stream": (vp, [vp]),
+        "rt_profile_begin": (C.c_int, [vp]),
+        "rt_profile_end": (C.c_int, [vp, vp, vp, vp]),
     }
     for name in SYMBOLS:
         fn = getattr(L, name)          # AttributeError here = the library does not export a declared symbol

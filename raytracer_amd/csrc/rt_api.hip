@@ -38,6 +38,12 @@ struct rt_ctx {
   hipEvent_t ev[8] = {};
   std::string err;
 
+  // rt_profile_begin/end: ring of event quadruples {frame begin, k_render begin, k_render end, frame end}
+  static constexpr uint32_t PROF_RING = 256;
+  std::vector<hipEvent_t> prof_ev;
+  bool prof_on = false;
+  uint32_t prof_n = 0;
+
   // mesh (loadObj contract)
   DevBuf<float> pos, nor;
   DevBuf<uint32_t> vidx, nidx;
@@ -148,6 +154,7 @@ extern "C" void rt_destroy(rt_ctx* ctx) {
   ctx->wide.release(); ctx->tri_pre.release();
   ctx->r_tile_counter.release(); ctx->r_list.release(); ctx->r_stats.release(); ctx->o_rgba.release(); ctx->o_tri.release(); ctx->o_t.release();
   for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : ctx->prof_ev) if (ev) (void)hipEventDestroy(ev);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -495,11 +502,14 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
   hipStream_t s = ctx->stream;
   HIPCHK(hipMemsetAsync(p.shard_heads, 0, sizeof(uint32_t) * (rt_shard_words() + 32), s));
   HIPCHK(hipMemsetAsync(p.stats, 0, sizeof(unsigned long long) * 8, s));
+  hipEvent_t* E = nullptr;   // {frame begin, k_render begin, k_render end, frame end}
+  if (ctx->prof_on) { E = &ctx->prof_ev[4 * (size_t)(ctx->prof_n % rt_ctx::PROF_RING)]; ctx->prof_n += (p.n_tiles > 0); }
+  else if (out) E = ctx->ev;
   if (p.n_tiles > 0) {
-    if (out) HIPCHK(hipEventRecord(ctx->ev[0], s));
-    rt_launch_render(p, opts->layout, (opts->flags & RT_FLAG_COUNT_WORK) != 0, ctx->n_cu, s);
+    if (E) HIPCHK(hipEventRecord(E[0], s));
+    rt_launch_render(p, opts->layout, (opts->flags & RT_FLAG_COUNT_WORK) != 0, ctx->n_cu, s, E ? E[1] : nullptr, E ? E[2] : nullptr);
     HIPCHK(hipGetLastError());
-    if (out) HIPCHK(hipEventRecord(ctx->ev[1], s));
+    if (E) HIPCHK(hipEventRecord(E[3], s));
   }
   if (out) {
     unsigned long long st[8];
@@ -508,8 +518,42 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
     std::memset(out, 0, sizeof(*out));
     out->rays_primary = st[0]; out->rays_shadow = st[1]; out->rays_bounce = st[2];
     out->box_tests = st[3]; out->tri_tests = st[4]; out->hit_updates = st[5]; out->pixels = st[6]; out->stack_drops = st[7];
-    if (p.n_tiles > 0) (void)hipEventElapsedTime(&out->ms_kernel, ctx->ev[0], ctx->ev[1]);
+    if (p.n_tiles > 0) {
+      (void)hipEventElapsedTime(&out->ms_kernel, E[0], E[3]);
+      (void)hipEventElapsedTime(&out->ms_traverse, E[1], E[2]);
+    }
   }
+  return RT_OK;
+}
+
+extern "C" int rt_profile_begin(rt_ctx* ctx) {
+  if (!ctx) return RT_ERR_INVALID;
+  DeviceGuard g(ctx->device);
+  if (ctx->prof_ev.empty()) {
+    ctx->prof_ev.resize(4 * (size_t)rt_ctx::PROF_RING, nullptr);
+    for (auto& e : ctx->prof_ev) HIPCHK(hipEventCreate(&e));
+  }
+  ctx->prof_on = true; ctx->prof_n = 0;
+  return RT_OK;
+}
+
+extern "C" int rt_profile_end(rt_ctx* ctx, float* ms_frame_avg, float* ms_traverse_avg, uint32_t* n_frames) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (!ctx->prof_on) return ctx->fail(RT_ERR_INVALID, "rt_profile_end without rt_profile_begin");
+  DeviceGuard g(ctx->device);
+  ctx->prof_on = false;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  const uint32_t n = std::min<uint32_t>(ctx->prof_n, rt_ctx::PROF_RING);   // the ring keeps the last PROF_RING frames
+  double fsum = 0.0, tsum = 0.0;
+  for (uint32_t i = 0; i < n; ++i) {
+    float a = 0.f, b = 0.f;
+    HIPCHK(hipEventElapsedTime(&a, ctx->prof_ev[4 * (size_t)i + 0], ctx->prof_ev[4 * (size_t)i + 3]));
+    HIPCHK(hipEventElapsedTime(&b, ctx->prof_ev[4 * (size_t)i + 1], ctx->prof_ev[4 * (size_t)i + 2]));
+    fsum += a; tsum += b;
+  }
+  if (ms_frame_avg) *ms_frame_avg = n ? (float)(fsum / n) : 0.f;
+  if (ms_traverse_avg) *ms_traverse_avg = n ? (float)(tsum / n) : 0.f;
+  if (n_frames) *n_frames = n;
   return RT_OK;
 }
 

@@ -94,6 +94,8 @@ uint32_t rt_render_grid(int n_cu);   // blocks of the persistent phase-B grid
 uint32_t rt_cull_blocks(uint32_t n_tiles);
 uint32_t rt_shard_words();
 uint32_t rt_shard_stride();
-void rt_launch_render(const RtRenderParams& p, int layout, bool count_work, int n_cu, hipStream_t s);
+// ev0/ev1 (optional) are recorded immediately before/after the traversal kernel proper
+void rt_launch_render(const RtRenderParams& p, int layout, bool count_work, int n_cu, hipStream_t s,
+                      hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 void rt_launch_deinterleave(const void* packed, void* image, uint32_t width, uint32_t height, uint32_t elem_bytes,
                             int stripe_rows, int world, uint32_t rows_per_rank, hipStream_t s);

@@ -643,12 +643,13 @@ uint32_t rt_shard_words() { return N_SHARD * (uint32_t)shard_stride_words(); }
 uint32_t rt_shard_stride() { return (uint32_t)shard_stride_words(); }
 
 // The caller zeroes shard_heads; masks / block_total / list / list_count are fully rewritten.
-void rt_launch_render(const RtRenderParams& p, int layout, bool count_work, int n_cu, hipStream_t s) {
+void rt_launch_render(const RtRenderParams& p, int layout, bool count_work, int n_cu, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
   const dim3 b(TBLK), gc(rt_cull_blocks(p.n_tiles));
   hipLaunchKernelGGL(k_cull, gc, b, 0, s, p);
   hipLaunchKernelGGL(k_compact, gc, b, 0, s, p);
   const dim3 g(resident_grid(n_cu, p.max_stack));
   const size_t lds = (size_t)p.max_stack * TBLK * (sizeof(uint32_t) + sizeof(float));
+  if (ev0) (void)hipEventRecord(ev0, s);
   if (layout == RT_LAYOUT_WIDE64) {
     if (count_work) hipLaunchKernelGGL((k_render<RT_LAYOUT_WIDE64, true>), g, b, lds, s, p);
     else hipLaunchKernelGGL((k_render<RT_LAYOUT_WIDE64, false>), g, b, lds, s, p);
@@ -656,6 +657,7 @@ void rt_launch_render(const RtRenderParams& p, int layout, bool count_work, int 
     if (count_work) hipLaunchKernelGGL((k_render<RT_LAYOUT_AOS32, true>), g, b, lds, s, p);
     else hipLaunchKernelGGL((k_render<RT_LAYOUT_AOS32, false>), g, b, lds, s, p);
   }
+  if (ev1) (void)hipEventRecord(ev1, s);
   hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(256), 0, s, p, g.x, p.local_rows * p.width, count_work ? 1 : 0);
 }
 

@@ -34,19 +34,30 @@ class GpuBackend:
 
     def __init__(self, ctx, device):
         self.ctx, self.device = ctx, device
+        # the context's own HIP stream, seen from torch, so that the two can be ordered with events
+        # (stream waits) instead of host synchronisation
+        self.ext = torch.cuda.ExternalStream(ctx.stream(), device=device)
 
     def alloc(self, rows, width):
         return torch.zeros((rows, width), dtype=torch.int32, device=self.device)
 
-    def render_packed(self, U, opts, packed):
-        st = self.ctx.render_device(U, opts, d_rgba8=packed.data_ptr(), want_stats=True)   # syncs the context stream
-        return st
+    def render_packed(self, U, opts, packed, want_stats=True):
+        """want_stats=True synchronises the context stream (stats are read back); False is fully asynchronous."""
+        return self.ctx.render_device(U, opts, d_rgba8=packed.data_ptr(), want_stats=want_stats)
+
+    def before_gather(self):
+        # the collective (torch's stream) must see the finished stripes (context stream)
+        torch.cuda.current_stream(self.device).wait_stream(self.ext)
 
     def deinterleave(self, gathered, image, width, height, world, rpr):
-        # the collective ran on torch's streams, the de-interleave kernel runs on the context's stream
-        torch.cuda.current_stream(self.device).synchronize()
+        # the de-interleave kernel, and the next frame's render into `packed`, run on the context's stream
+        # after the collective on torch's stream
+        self.ext.wait_stream(torch.cuda.current_stream(self.device))
         self.ctx.deinterleave_device(gathered.data_ptr(), image.data_ptr(), width, height, 4, STRIPE_ROWS, world, rpr)
+
+    def finish(self):
         self.ctx.synchronize()
+        torch.cuda.current_stream(self.device).synchronize()
 
 
 def replicate_bvh(ctx, rank, world, device):
@@ -74,21 +85,31 @@ def replicate_bvh(ctx, rank, world, device):
 class ShardedFrame:
     """One frame sharded as image-space stripes over `world` ranks and gathered on every rank."""
 
-    def __init__(self, backend, width, height, rank, world, base_opts=None):
+    def __init__(self, backend, width, height, rank, world, base_opts=None, force_collective=False):
+        """force_collective: run the gather + de-interleave leg even at world == 1 (tests the stream plumbing on one GPU)."""
         self.b, self.w, self.h, self.rank, self.world = backend, width, height, rank, world
+        self.collective = world > 1 or force_collective
         self.rpr = rows_per_rank(height, world) if world > 1 else height
         o = base_opts or render_opts()
         self.opts = render_opts(mode=o.mode, gi_samples=o.gi_samples, gi_bounces=o.gi_bounces, soft_samples=o.soft_samples,
                                 max_stack=o.max_stack, layout=o.layout, flags=o.flags,
                                 stripe_rows=STRIPE_ROWS if world > 1 else 0, stripe_rank=rank, stripe_world=world)
         self.packed = backend.alloc(self.rpr, width)
-        self.gathered = backend.alloc(self.rpr * world, width) if world > 1 else None
-        self.image = backend.alloc(height, width) if world > 1 else self.packed
+        self.gathered = backend.alloc(self.rpr * world, width) if self.collective else None
+        self.image = backend.alloc(height, width) if self.collective else self.packed
 
-    def step(self, U):
-        """Render my stripes, gather all stripes, de-interleave.  Returns this rank's render stats."""
-        st = self.b.render_packed(U, self.opts, self.packed)
-        if self.world > 1:
+    def step(self, U, want_stats=True):
+        """Render my stripes, gather all stripes, de-interleave.  Returns this rank's render stats (or None).
+        With want_stats=False nothing synchronises with the host: call finish() before reading self.image."""
+        st = self.b.render_packed(U, self.opts, self.packed, want_stats) if not want_stats else \
+            self.b.render_packed(U, self.opts, self.packed)
+        if self.collective:
+            if hasattr(self.b, "before_gather"):
+                self.b.before_gather()
             dist.all_gather_into_tensor(self.gathered, self.packed)
             self.b.deinterleave(self.gathered, self.image, self.w, self.h, self.world, self.rpr)
         return st
+
+    def finish(self):
+        if hasattr(self.b, "finish"):
+            self.b.finish()

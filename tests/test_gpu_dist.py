@@ -1,0 +1,57 @@
+"""The multi-GPU frame loop's stream plumbing on ONE GPU: a world_size-1 RCCL group with the
+gather + de-interleave leg forced on, frames queued without host synchronisation (the path
+bench.py times), against the synchronous single-call frame.  The N>1 host logic itself
+(stripe ownership, packed layout, gather order) is covered on CPU by tests/test_dist_cpu.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PLANE_VIEW = dict(cam_pos=(0.0, 0.0, 1.3), rot_deg=(-90.0, 0.0, 0.0), scale=(2.5, 2.5, 2.5))
+
+
+@pytest.fixture(scope="module")
+def nccl_world1():
+    import os
+    import socket
+
+    import torch
+    import torch.distributed as dist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda:0"))
+    yield dist
+    dist.destroy_process_group()
+
+
+def test_async_frames_with_forced_collective(gpu_ctx, rt, plane_mesh, nccl_world1):
+    import torch
+
+    from raytracer_amd import dist as rdist
+    gpu_ctx.set_mesh(plane_mesh)
+    gpu_ctx.build_lbvh()
+    w, h = 320, 200
+    opts = rt.render_opts(mode=rt.MODE_SHADOW)
+    dev = torch.device("cuda:0")
+    frame = rdist.ShardedFrame(rdist.GpuBackend(gpu_ctx, dev), w, h, 0, 1, opts, force_collective=True)
+    views = [dict(PLANE_VIEW), dict(PLANE_VIEW, cam_pos=(0.1, 0.0, 1.2)), dict(PLANE_VIEW, rot_deg=(-70.0, 10.0, 0.0))]
+    gpu_ctx.profile_begin()
+    for k in range(9):                      # queued back to back: render k+1 must not overwrite stripes still being gathered
+        frame.step(rt.make_uniforms(w, h, **views[k % 3]), want_stats=False)
+    frame.finish()
+    ms_frame, ms_trav, n = gpu_ctx.profile_end()
+    assert n == 9 and 0.0 < ms_trav <= ms_frame
+    got = frame.image.cpu().numpy().view(np.uint8).reshape(h, w, 4)
+    ref, _ = gpu_ctx.render(rt.make_uniforms(w, h, **views[8 % 3]), opts, want=("rgba8",))
+    assert np.array_equal(got, ref["rgba8"])
+    assert (ref["rgba8"][..., :3].max(axis=2) > 0).mean() > 0.05
+
+
+def test_profile_end_needs_begin(gpu_ctx, rt):
+    with pytest.raises(rt.RtError):
+        gpu_ctx.profile_end()
