@@ -151,13 +151,15 @@ def main():
         value = total_rays * args.steps / elapsed / 1e6
         # roofline of the dominant kernel (traversal): this rank's algorithmic bytes / its average launch duration
         achieved = my_bytes / (trav_ms * 1e-3) / 1e9 if trav_ms > 0 else 0.0
+        what = {"primary": "primary rays only", "shadow": "primary + 4 soft shadow rays",
+                "pt": f"full computeLighting_optimized: GI {args.spp} spp x 3 bounces + 4 soft shadow rays per vertex"}[args.mode]
         out = {
             "metric": "Mrays/s primary+shadow, dragon.obj 4K" if args.mode == "shadow" else f"Mrays/s {args.mode}",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"cfg3: {args.scene.upper()} stand-in for dragon.obj ({build['n_tri']} triangles, closed-form "
-                                   f"icosphere), {W}x{H}, primary + 4 soft shadow rays, camera B (0,0,1.3), layout {args.layout}",
+                                   f"icosphere), {W}x{H}, {what}, camera B (0,0,1.3), layout {args.layout}",
                        "mode": args.mode, "rays_per_frame": int(total_rays), "stripes": "16-row round-robin" if world > 1 else "none"},
             "lbvh_build_ms": {k: round(float(v), 4) for k, v in build.items() if k.startswith("ms_")},
             "lbvh_build_roofline_frac": round(build["algorithmic_bytes"] / (build["ms_total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),

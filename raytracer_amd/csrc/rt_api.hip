@@ -102,6 +102,7 @@ int finish_bvh(rt_ctx* ctx) {   // derive the traversal layout from the intercha
   HIPCHK(hipGetLastError());
   uint32_t w[2] = {0, 0};
   HIPCHK(hipMemcpyAsync(w, ctx->words.p, sizeof(w), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(b.root_box, b.nodes, sizeof(b.root_box), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (w[1] & 2u) return ctx->fail(RT_ERR_LIMIT, "leaf start/count exceeds the WIDE64 reference encoding (start < 2^23, count <= 256)");
   if (w[1] & 4u) return ctx->fail(RT_ERR_INVALID, "node buffer has an out-of-range child index");
@@ -500,14 +501,14 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
   p.stats = ctx->r_stats.p; p.stats_partial = ctx->r_stats.p + 8;
   p.masks = ctx->r_stats.p + 8 + (size_t)rt_render_grid(ctx->n_cu) * 8;
   hipStream_t s = ctx->stream;
-  HIPCHK(hipMemsetAsync(p.shard_heads, 0, sizeof(uint32_t) * (rt_shard_words() + 32), s));
-  HIPCHK(hipMemsetAsync(p.stats, 0, sizeof(unsigned long long) * 8, s));
+  rt_cull_rect(p, ctx->bvh.root_box);
+  if (out && p.n_tiles == 0) HIPCHK(hipMemsetAsync(p.stats, 0, sizeof(unsigned long long) * 8, s));
   hipEvent_t* E = nullptr;   // {frame begin, k_render begin, k_render end, frame end}
   if (ctx->prof_on) { E = &ctx->prof_ev[4 * (size_t)(ctx->prof_n % rt_ctx::PROF_RING)]; ctx->prof_n += (p.n_tiles > 0); }
   else if (out) E = ctx->ev;
   if (p.n_tiles > 0) {
     if (E) HIPCHK(hipEventRecord(E[0], s));
-    rt_launch_render(p, opts->layout, (opts->flags & RT_FLAG_COUNT_WORK) != 0, ctx->n_cu, s, E ? E[1] : nullptr, E ? E[2] : nullptr);
+    rt_launch_render(p, opts->layout, (opts->flags & RT_FLAG_COUNT_WORK) != 0, out != nullptr, ctx->n_cu, s, E ? E[1] : nullptr, E ? E[2] : nullptr);
     HIPCHK(hipGetLastError());
     if (E) HIPCHK(hipEventRecord(E[3], s));
   }

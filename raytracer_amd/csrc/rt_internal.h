@@ -32,6 +32,7 @@ struct RtBvhDev {
   uint32_t root_ref = 0;     // traversal ref of node 0
   int      leaf_shift = 23;
   bool     owns_interchange = true;
+  float    root_box[8] = {};   // host copy of node 0 (mn.xyz, A | mx.xyz, B) for the screen-space cull rectangle
 };
 
 struct RtRenderParams {
@@ -48,6 +49,9 @@ struct RtRenderParams {
   uint32_t width, height;
   int stripe_rows, stripe_rank, stripe_world;   // stripe_rows == 0: whole image
   uint32_t tiles_x, n_tiles, local_rows;
+  // inclusive pixel rectangle (global image coordinates) that conservatively contains every pixel whose
+  // primary ray can enter the root box; tiles outside it are final without generating rays (x1 < x0: empty)
+  int cull_x0, cull_x1, cull_y0, cull_y1;
   uint8_t*  rgba8;     // packed local rows
   uint32_t* hit_tri;
   float*    hit_t;
@@ -95,7 +99,10 @@ uint32_t rt_cull_blocks(uint32_t n_tiles);
 uint32_t rt_shard_words();
 uint32_t rt_shard_stride();
 // ev0/ev1 (optional) are recorded immediately before/after the traversal kernel proper
-void rt_launch_render(const RtRenderParams& p, int layout, bool count_work, int n_cu, hipStream_t s,
+// want_stats == false skips the k_stats_final reduction (p.stats is then not written)
+void rt_launch_render(const RtRenderParams& p, int layout, bool count_work, bool want_stats, int n_cu, hipStream_t s,
                       hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+// Conservative screen-space bound of the root box (host, double precision): fills p.cull_*.
+void rt_cull_rect(RtRenderParams& p, const float root_box[8]);
 void rt_launch_deinterleave(const void* packed, void* image, uint32_t width, uint32_t height, uint32_t elem_bytes,
                             int stripe_rows, int world, uint32_t rows_per_rank, hipStream_t s);

@@ -14,6 +14,8 @@
 // Semantics kept exactly: test order, near-child rule `b0.x <= b1.x`, the MAX_STACK-1 push
 // guard that silently drops the far child (F9), strict `<` closest-hit update, front-face
 // only Möller–Trumbore, child0-chain shadow walk (F8), shared RNG sequence (F7).
+#include <cmath>
+
 #include "rt_device.h"
 #include "rt_internal.h"
 
@@ -462,7 +464,8 @@ __global__ void k_stats_final(const RtRenderParams p, uint32_t n_blocks, uint32_
 // 267 us of a 325 us launch), so the compaction is atomic-free and the phase-B queue is sharded.
 constexpr int CULL_TPB = 64;          // tiles per k_cull / k_compact block: 16 rounds x 4 waves
 constexpr int N_SHARD = 64;           // phase-B queue shards, one 128-byte line each
-static int shard_stride_words() { return 32; }   // uint32 words between shard heads: one 128-byte line each
+constexpr int SHARD_STRIDE = 32;      // uint32 words between shard heads: one 128-byte line each
+static int shard_stride_words() { return SHARD_STRIDE; }
 
 // Phase A1 — cull.  One lane per pixel of an 8x8 tile.  A primary ray that misses the root box
 // (compute.wgsl:275 on node 0) can never hit anything: its pixel is final here ((0,0,0,1),
@@ -471,6 +474,8 @@ __global__ __launch_bounds__(TBLK) void k_cull(const RtRenderParams p) {
   __shared__ uint32_t s_cnt[CULL_TPB];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float4 ra = reinterpret_cast<const float4*>(p.nodes)[0], rb = reinterpret_cast<const float4*>(p.nodes)[1];
+  if (blockIdx.x == 0)   // phase-B queue heads start at zero (k_render runs two launches later)
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(N_SHARD * SHARD_STRIDE); i += TBLK) p.shard_heads[i] = 0u;
 #pragma unroll 1
   for (int r = 0; r < CULL_TPB / (TBLK / 64); ++r) {
     const int k = r * (TBLK / 64) + w;                       // the 4 waves of a block work on 4 adjacent tiles
@@ -483,9 +488,15 @@ __global__ __launch_bounds__(TBLK) void k_cull(const RtRenderParams p) {
       bool enters = false;
       if (x < p.width && lrow < p.local_rows && y < p.height) {
         const uint32_t idx = lrow * p.width + x;
-        const PrimaryRay pr = primary_ray(p.U, x, y, p.width, p.height);
-        float tn, tf; slab(pr.ro, pr.inv, xyz(ra), xyz(rb), tn, tf);
-        enters = box_hit(tn, tf, 1e20f);
+        // tiles wholly outside the conservative screen rectangle of the root box need no ray (wave-uniform test:
+        // a tile's 8 rows are contiguous in the global image because stripes are multiples of 8 rows)
+        const int tx0 = (int)(tx * 8u), ty0 = (int)local_to_global_row(p, ty * 8u);
+        const bool tile_in = tx0 <= p.cull_x1 && tx0 + 7 >= p.cull_x0 && ty0 <= p.cull_y1 && ty0 + 7 >= p.cull_y0;
+        if (tile_in) {
+          const PrimaryRay pr = primary_ray(p.U, x, y, p.width, p.height);
+          float tn, tf; slab(pr.ro, pr.inv, xyz(ra), xyz(rb), tn, tf);
+          enters = box_hit(tn, tf, 1e20f);
+        }
         if (!enters) {                                        // ray / box-test / pixel counts: k_stats_final
           if (p.rgba8) reinterpret_cast<uint32_t*>(p.rgba8)[idx] = 0xFF000000u;
           if (p.hit_tri) p.hit_tri[idx] = 0xFFFFFFFFu;
@@ -642,8 +653,57 @@ uint32_t rt_cull_blocks(uint32_t n_tiles) { return (n_tiles + CULL_TPB - 1) / CU
 uint32_t rt_shard_words() { return N_SHARD * (uint32_t)shard_stride_words(); }
 uint32_t rt_shard_stride() { return (uint32_t)shard_stride_words(); }
 
-// The caller zeroes shard_heads; masks / block_total / list / list_count are fully rewritten.
-void rt_launch_render(const RtRenderParams& p, int layout, bool count_work, int n_cu, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+// k_cull zeroes shard_heads; masks / block_total / list / list_count / stats are fully rewritten.
+// Screen-space rectangle of the root box.  A primary ray through pixel-plane point s = (sx, sy, 1) has
+// object-space direction A s, A = M3 [camRight camUp camForward] (primary_ray above), origin o = M (cam, 1).
+// A box point c reached at t >= 0 satisfies A^-1 (c - o) = lambda (sx, sy, 1) with lambda > 0, so when all 8
+// corners have lambda > 0 every entering ray's (sx, sy) lies in the convex hull of the corner projections,
+// hence in their bounding rectangle.  Two pixels of padding absorb f32 rounding of the device's ray set-up
+// (< 1e-3 pixel).  Anything else (camera inside / beside the box, singular A, NaN) keeps the full image.
+void rt_cull_rect(RtRenderParams& p, const float rb[8]) {
+  p.cull_x0 = 0; p.cull_y0 = 0; p.cull_x1 = (int)p.width - 1; p.cull_y1 = (int)p.height - 1;
+  const float* U = p.U;
+  const float* m = U + 20;
+  double A[3][3], o[3];
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) {
+      const float* v = U + 8 + 4 * c;   // camRight @8, camUp @12, camForward @16
+      A[r][c] = (double)m[r] * v[0] + (double)m[4 + r] * v[1] + (double)m[8 + r] * v[2];
+    }
+    o[r] = (double)m[r] * U[0] + (double)m[4 + r] * U[1] + (double)m[8 + r] * U[2] + (double)m[12 + r];
+  }
+  const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                     A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+  double amax = 0.0;
+  for (auto& row : A) for (double v : row) amax = std::fmax(amax, std::fabs(v));
+  if (!(std::fabs(det) > 1e-12 * amax * amax * amax) || !(amax > 0.0)) return;
+  double inv[3][3];
+  inv[0][0] = (A[1][1] * A[2][2] - A[1][2] * A[2][1]) / det; inv[0][1] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) / det;
+  inv[0][2] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) / det; inv[1][0] = (A[1][2] * A[2][0] - A[1][0] * A[2][2]) / det;
+  inv[1][1] = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) / det; inv[1][2] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) / det;
+  inv[2][0] = (A[1][0] * A[2][1] - A[1][1] * A[2][0]) / det; inv[2][1] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) / det;
+  inv[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) / det;
+  double sx0 = 1e300, sx1 = -1e300, sy0 = 1e300, sy1 = -1e300;
+  for (int k = 0; k < 8; ++k) {
+    const double c[3] = {(double)rb[(k & 1) ? 4 : 0] - o[0], (double)rb[(k & 2) ? 5 : 1] - o[1], (double)rb[(k & 4) ? 6 : 2] - o[2]};
+    double q[3];
+    for (int r = 0; r < 3; ++r) q[r] = inv[r][0] * c[0] + inv[r][1] * c[1] + inv[r][2] * c[2];
+    const double qm = std::fmax(std::fabs(q[0]), std::fmax(std::fabs(q[1]), std::fabs(q[2])));
+    if (!(q[2] > 1e-6 * qm) || !(qm < 1e300)) return;                     // corner beside / behind the eye, or NaN
+    sx0 = std::fmin(sx0, q[0] / q[2]); sx1 = std::fmax(sx1, q[0] / q[2]);
+    sy0 = std::fmin(sy0, q[1] / q[2]); sy1 = std::fmax(sy1, q[1] / q[2]);
+  }
+  // sx = 2 (x + 0.5) / w - 1  =>  x = (sx + 1) w / 2 - 0.5
+  const double W = (double)p.width, H = (double)p.height, pad = 2.0;
+  const double x0 = std::floor((sx0 + 1.0) * 0.5 * W - 0.5 - pad), x1 = std::ceil((sx1 + 1.0) * 0.5 * W - 0.5 + pad);
+  const double y0 = std::floor((sy0 + 1.0) * 0.5 * H - 0.5 - pad), y1 = std::ceil((sy1 + 1.0) * 0.5 * H - 0.5 + pad);
+  if (!(x0 == x0) || !(x1 == x1) || !(y0 == y0) || !(y1 == y1)) return;
+  p.cull_x0 = (int)std::fmax(0.0, std::fmin(x0, W));  p.cull_x1 = (int)std::fmin(W - 1.0, std::fmax(x1, -1.0));
+  p.cull_y0 = (int)std::fmax(0.0, std::fmin(y0, H));  p.cull_y1 = (int)std::fmin(H - 1.0, std::fmax(y1, -1.0));
+}
+
+void rt_launch_render(const RtRenderParams& p, int layout, bool count_work, bool want_stats, int n_cu, hipStream_t s, hipEvent_t ev0,
+                      hipEvent_t ev1) {
   const dim3 b(TBLK), gc(rt_cull_blocks(p.n_tiles));
   hipLaunchKernelGGL(k_cull, gc, b, 0, s, p);
   hipLaunchKernelGGL(k_compact, gc, b, 0, s, p);
@@ -658,7 +718,7 @@ void rt_launch_render(const RtRenderParams& p, int layout, bool count_work, int 
     else hipLaunchKernelGGL((k_render<RT_LAYOUT_AOS32, false>), g, b, lds, s, p);
   }
   if (ev1) (void)hipEventRecord(ev1, s);
-  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(256), 0, s, p, g.x, p.local_rows * p.width, count_work ? 1 : 0);
+  if (want_stats) hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(256), 0, s, p, g.x, p.local_rows * p.width, count_work ? 1 : 0);
 }
 
 void rt_launch_deinterleave(const void* packed, void* image, uint32_t width, uint32_t height, uint32_t elem_bytes,

@@ -139,3 +139,29 @@ def test_imported_bvh_and_cache_file(gpu_ctx, oracle, rt, plane_mesh, tmp_path):
         ctx2.close()
     for k in a:
         assert np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k])
+
+
+def test_cull_rectangle_is_conservative(gpu_ctx, oracle, rt, plane_mesh):
+    """k_cull skips tiles outside a host-computed screen rectangle of the root box.  Cameras outside, inside,
+    beside and facing away from the box, odd image sizes, rotated / scaled / translated models: the frame must
+    still equal the oracle's pixel for pixel."""
+    ref_b = _scene(gpu_ctx, oracle, plane_mesh)
+    rng = np.random.default_rng(5)
+    views = [dict(cam_pos=(0.0, 0.0, 5.0)), dict(cam_pos=(0.0, 0.0, 0.0)), dict(cam_pos=(0.2, 0.1, 0.45), yaw=0.3),
+             dict(cam_pos=(0.0, 0.0, -2.0)), dict(cam_pos=(3.0, 0.0, 0.0), yaw=-1.57), dict(cam_pos=(0.0, 0.0, 1.0), pitch=1.2)]
+    for _ in range(10):
+        views.append(dict(cam_pos=tuple(rng.uniform(-2, 2, 3)), yaw=float(rng.uniform(-3.2, 3.2)), pitch=float(rng.uniform(-1.4, 1.4)),
+                          rot_deg=tuple(rng.uniform(-180, 180, 3)), scale=tuple(rng.uniform(0.3, 3.0, 3)),
+                          translate=tuple(rng.uniform(-0.5, 0.5, 3))))
+    seen = 0
+    for i, v in enumerate(views):
+        w, h = [(97, 65), (160, 96), (64, 64)][i % 3]
+        U = rt.make_uniforms(w, h, **v)
+        out, st = gpu_ctx.render(U, rt.render_opts(mode=rt.MODE_PRIMARY, flags=rt.FLAG_COUNT_WORK))
+        ref, rst = oracle.render(ref_b["nodes"], ref_b["tri_pos"], ref_b["tri_nor"], U, mode=0, n_threads=8)
+        _compare(out, ref, f"view {i}")
+        assert np.array_equal(out["rgba8"], ref["rgba8"])
+        for k in COUNT_KEYS:
+            assert st[k] == rst[k], f"view {i} {k}: gpu {st[k]} vs oracle {rst[k]}"
+        seen += int((ref["hit_tri"] != 0xFFFFFFFF).any())
+    assert seen >= 5
