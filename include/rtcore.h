@@ -111,6 +111,17 @@ int  rt_make_uniforms(const rt_camera* cam, float out44[44]);
 int rt_set_mesh(rt_ctx* ctx, const float* positions, uint32_t n_vert, const float* normals, uint32_t n_nor,
                 const uint32_t* vert_idx, const uint32_t* nor_idx, uint32_t n_tri);
 
+/* Node-record encoding of slots A / B of the 32-byte record (flattenForSSBO, script.js:546-559).
+ * RT_NODES_V1 (default) is the reference's: child / triangle indices as f32 VALUES, leaf B = -count; exact
+ * only below 2^24 nodes, larger builds return RT_ERR_LIMIT.  RT_NODES_V2 keeps
+ * the record and its size and stores u32 bit-casts in the same slots: internal A = child0, B = child1
+ * (bit 31 clear); leaf A = tri_start, B = 0x80000000 | tri_count.  Up to 2^28 triangles.  The setting applies
+ * to the next rt_build_lbvh / rt_set_bvh / rt_load_bvh / rt_bvh_adopt_device and to what rt_get_nodes,
+ * rt_save_bvh and rt_bvh_export_device hand out (the buffer is kept in the encoding it was made in). */
+enum { RT_NODES_V1 = 1, RT_NODES_V2 = 2 };
+int rt_set_node_encoding(rt_ctx* ctx, int encoding);
+int rt_get_node_encoding(rt_ctx* ctx);   /* of the current BVH if there is one, else the setting */
+
 typedef struct rt_build_stats {
   float ms_bounds, ms_morton, ms_sort, ms_tree, ms_refit, ms_pack, ms_total;  /* hipEvent times */
   uint32_t n_tri, n_nodes;

@@ -18,7 +18,7 @@ MODE_PRIMARY, MODE_SHADOW, MODE_PT = 0, 1, 2
 class RenderOpts(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "mode", "gi_samples", "gi_bounces", "soft_samples", "max_stack",
-        "row_begin", "row_end", "row_step", "n_threads")]
+        "row_begin", "row_end", "row_step", "n_threads", "node_encoding")]
 
 
 class RenderStats(C.Structure):
@@ -60,6 +60,8 @@ def lib():
         L.orc_build_lbvh.restype = None
         L.orc_build_lbvh.argtypes = [f32p, C.c_uint32, f32p, C.c_uint32, u32p, u32p, C.c_uint32,
                                      f32p, f32p, f32p, u32p, u32p, C.POINTER(C.c_double)]
+        L.orc_build_lbvh_enc.restype = None
+        L.orc_build_lbvh_enc.argtypes = L.orc_build_lbvh.argtypes + [C.c_int]
         L.orc_make_uniforms.restype = None
         L.orc_make_uniforms.argtypes = [C.POINTER(C.c_double), C.c_double, C.c_double, C.POINTER(C.c_double),
                                         C.c_uint32, C.c_uint32, C.c_float, f32p]
@@ -123,8 +125,9 @@ def karras(sorted_codes):
     return c0[:max(T - 1, 0)], c1[:max(T - 1, 0)], par
 
 
-def build_lbvh(pos, nor, vidx, nidx):
-    """Returns dict(nodes[N,8], tri_pos[T,3,4], tri_nor[T,3,4], codes[T], order[T], seconds)."""
+def build_lbvh(pos, nor, vidx, nidx, encoding=1):
+    """Returns dict(nodes[N,8], tri_pos[T,3,4], tri_nor[T,3,4], codes[T], order[T], seconds).
+    encoding: 1 = v1 node records (reference), 2 = v2 (u32 bit-casts; needed above 2^24 nodes)."""
     p, v = _mesh(pos, vidx)
     n, ni = _mesh(nor, nidx)
     T = v.size // 3
@@ -132,7 +135,7 @@ def build_lbvh(pos, nor, vidx, nidx):
     tp, tn = np.zeros(T * 12, np.float32), np.zeros(T * 12, np.float32)
     codes, order = np.zeros(T, np.uint32), np.zeros(T, np.uint32)
     sec = C.c_double()
-    lib().orc_build_lbvh(p, p.size // 3, n, n.size // 3, v, ni, T, nodes, tp, tn, codes, order, C.byref(sec))
+    lib().orc_build_lbvh_enc(p, p.size // 3, n, n.size // 3, v, ni, T, nodes, tp, tn, codes, order, C.byref(sec), encoding)
     return dict(nodes=nodes.reshape(-1, 8), tri_pos=tp.reshape(T, 3, 4), tri_nor=tn.reshape(T, 3, 4),
                 codes=codes, order=order, seconds=sec.value)
 
@@ -149,7 +152,7 @@ def make_uniforms(cam_pos=(0.0, 0.0, 5.0), yaw=0.0, pitch=0.0, sliders=DEFAULT_S
 
 
 def render(nodes, tri_pos, tri_nor, uniforms, mode=MODE_PRIMARY, gi_samples=32, gi_bounces=3, soft_samples=4,
-           max_stack=12, rows=None, n_threads=1, want=("rgba8", "hit_tri", "hit_t")):
+           max_stack=12, rows=None, n_threads=1, want=("rgba8", "hit_tri", "hit_t"), encoding=1):
     """rows = (begin, end, step) or None for all. Returns (outputs dict, stats dict)."""
     nodes = np.ascontiguousarray(nodes, np.float32).reshape(-1)
     tp = np.ascontiguousarray(tri_pos, np.float32).reshape(-1)
@@ -157,7 +160,7 @@ def render(nodes, tri_pos, tri_nor, uniforms, mode=MODE_PRIMARY, gi_samples=32, 
     U = np.ascontiguousarray(uniforms, np.float32)
     w, h = int(U[36]), int(U[37])
     rb, re_, rs = rows if rows is not None else (0, h, 1)
-    opts = RenderOpts(mode, gi_samples, gi_bounces, soft_samples, max_stack, rb, re_, rs, n_threads)
+    opts = RenderOpts(mode, gi_samples, gi_bounces, soft_samples, max_stack, rb, re_, rs, n_threads, encoding)
     out = {}
     if "rgba8" in want: out["rgba8"] = np.zeros((h, w, 4), np.uint8)
     if "hit_tri" in want: out["hit_tri"] = np.full((h, w), 0xFFFFFFFF, np.uint32)

@@ -162,10 +162,25 @@ extern "C" void orc_karras(const uint32_t* k, uint32_t n_tri, int32_t* child0, i
 }
 
 // bounds -> morton -> sort -> tree -> refit -> flat buffers
+// Node slots A (float 3) and B (float 7) of the 32-byte record:
+//   v1 (web/script.js:546-559): indices as f32 VALUES, leaf: A = tri_start, B = -count (< 0)  — exact below 2^24 (F11)
+//   v2:           u32 bit-casts in the same slots, leaf flag = bit 31 of B, low 31 bits = count
+static inline float bits_f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+static inline uint32_t f_bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+static inline float enc_index(int enc, uint32_t i) { return enc == 2 ? bits_f(i) : (float)i; }
+static inline float enc_leaf_b(int enc, uint32_t count) { return enc == 2 ? bits_f(0x80000000u | count) : -(float)count; }
+
 extern "C" void orc_build_lbvh(const float* pos, uint32_t n_vert, const float* nor, uint32_t n_nor,
                                const uint32_t* vidx, const uint32_t* nidx, uint32_t n_tri,
                                float* nodes, float* tri_pos, float* tri_nor,
                                uint32_t* codes_out, uint32_t* order_out, double* seconds) {
+  orc_build_lbvh_enc(pos, n_vert, nor, n_nor, vidx, nidx, n_tri, nodes, tri_pos, tri_nor, codes_out, order_out, seconds, 1);
+}
+
+extern "C" void orc_build_lbvh_enc(const float* pos, uint32_t n_vert, const float* nor, uint32_t n_nor,
+                                   const uint32_t* vidx, const uint32_t* nidx, uint32_t n_tri,
+                                   float* nodes, float* tri_pos, float* tri_nor,
+                                   uint32_t* codes_out, uint32_t* order_out, double* seconds, int enc) {
   (void)n_vert; (void)n_nor;
   auto t0 = std::chrono::steady_clock::now();
   const uint32_t T = n_tri;
@@ -183,9 +198,9 @@ extern "C" void orc_build_lbvh(const float* pos, uint32_t n_vert, const float* n
   for (uint32_t i = 0; i < T; ++i) {
     uint32_t ti = order[i];
     for (int v = 0; v < 3; ++v) {
-      uint32_t vi = vidx[3 * ti + v], ni = nidx[3 * ti + v];
-      float* dp = tri_pos + (size_t)(i * 3 + v) * 4;
-      float* dn = tri_nor + (size_t)(i * 3 + v) * 4;
+      const size_t vi = vidx[3 * (size_t)ti + v], ni = nidx[3 * (size_t)ti + v];
+      float* dp = tri_pos + ((size_t)i * 3 + v) * 4;
+      float* dn = tri_nor + ((size_t)i * 3 + v) * 4;
       dp[0] = pos[3 * vi + 0]; dp[1] = pos[3 * vi + 1]; dp[2] = pos[3 * vi + 2]; dp[3] = 0.0f;
       dn[0] = nor[3 * ni + 0]; dn[1] = nor[3 * ni + 1]; dn[2] = nor[3 * ni + 2]; dn[3] = 0.0f;
     }
@@ -199,8 +214,8 @@ extern "C" void orc_build_lbvh(const float* pos, uint32_t n_vert, const float* n
       nd[k] = fminf(fminf(p[k], p[4 + k]), p[8 + k]);
       nd[4 + k] = fmaxf(fmaxf(p[k], p[4 + k]), p[8 + k]);
     }
-    nd[3] = (float)j;
-    nd[7] = -1.0f;
+    nd[3] = enc_index(enc, j);
+    nd[7] = enc_leaf_b(enc, 1u);
   }
   // internal boxes bottom-up: process nodes in decreasing depth via an explicit post-order.
   if (T > 1) {
@@ -219,8 +234,8 @@ extern "C" void orc_build_lbvh(const float* pos, uint32_t n_vert, const float* n
         const float* b = nodes + (size_t)c1[n] * 8;
         float* nd = nodes + (size_t)n * 8;
         for (int k = 0; k < 3; ++k) { nd[k] = fminf(a[k], b[k]); nd[4 + k] = fmaxf(a[4 + k], b[4 + k]); }
-        nd[3] = (float)c0[n];   // indices stored as f32 VALUES (F11; web/script.js:554,558)
-        nd[7] = (float)c1[n];
+        nd[3] = enc_index(enc, (uint32_t)c0[n]);   // v1: indices stored as f32 VALUES (F11; web/script.js:554,558)
+        nd[7] = enc_index(enc, (uint32_t)c1[n]);
       }
     }
   }
@@ -398,6 +413,7 @@ struct Scene {
   const float* nodes; uint32_t n_nodes;
   const float* tri_pos; const float* tri_nor; uint32_t n_tri;
   int max_stack, gi_samples, gi_bounces, soft_samples, mode;
+  int enc;   // node record encoding: 1 = v1 (reference), 2 = v2
 };
 uint32_t* g_visit_counts = nullptr;        // analysis only, single-threaded use: internal steps per node
 struct Counters {
@@ -410,6 +426,13 @@ inline CachedNode fetch_node(const Scene& S, int idx) {
   const float* b = S.nodes + (size_t)(uint32_t)idx * 8;
   CachedNode n;
   n.mn = v3(b[0], b[1], b[2]); n.mx = v3(b[4], b[5], b[6]);
+  if (S.enc == 2) {   // v2: the same decode on u32 bit-casts
+    const uint32_t A = f_bits(b[3]), B = f_bits(b[7]);
+    n.is_leaf = (B >> 31) != 0;
+    if (n.is_leaf) { n.tri_start = (int)A; n.tri_count = (int)(B & 0x7FFFFFFFu); n.child0 = -1; n.child1 = -1; }
+    else { n.child0 = (int)A; n.child1 = (int)B; n.tri_start = -1; n.tri_count = 0; }
+    return n;
+  }
   n.is_leaf = (b[7] < 0.0f);
   if (n.is_leaf) { n.tri_start = sat_i32(b[3]); n.tri_count = -sat_i32(b[7]); n.child0 = -1; n.child1 = -1; }
   else { n.child0 = sat_i32(b[3]); n.child1 = sat_i32(b[7]); n.tri_start = -1; n.tri_count = 0; }
@@ -675,7 +698,8 @@ extern "C" int orc_render(const float* nodes, uint32_t n_nodes, const float* tri
   if (!nodes || !tri_pos || !tri_nor || !U || !o) return -1;
   if (o->max_stack < 1 || o->max_stack > 64 || o->row_step < 1) return -2;
   if (n_nodes == 0 || n_tri == 0) return -3;
-  Scene S{nodes, n_nodes, tri_pos, tri_nor, n_tri, o->max_stack, o->gi_samples, o->gi_bounces, o->soft_samples, o->mode};
+  Scene S{nodes, n_nodes, tri_pos, tri_nor, n_tri, o->max_stack, o->gi_samples, o->gi_bounces, o->soft_samples, o->mode,
+          o->node_encoding == 2 ? 2 : 1};
   const uint32_t w = sat_u32(U[36]), h = sat_u32(U[37]);
   const float time_h = (float)orc_hash_u32(sat_u32(U[38]));      // compute.wgsl:444
   int r0 = std::max(0, o->row_begin), r1 = std::min<int>((int)h, o->row_end), rs = o->row_step;

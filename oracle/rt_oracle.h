@@ -41,6 +41,7 @@ typedef struct orc_render_opts {
   int32_t row_end;
   int32_t row_step;
   int32_t n_threads;     /* std::thread row striping; 1 = scalar */
+  int32_t node_encoding; /* 0/1 = v1 records (indices as f32 values, reference), 2 = v2 (u32 bit-casts) */
 } orc_render_opts;
 
 typedef struct orc_render_stats {
@@ -86,6 +87,13 @@ void orc_build_lbvh(const float* pos, uint32_t n_vert, const float* nor, uint32_
                     const uint32_t* vidx, const uint32_t* nidx, uint32_t n_tri,
                     float* nodes, float* tri_pos, float* tri_nor,
                     uint32_t* codes, uint32_t* order, double* seconds);
+
+/* Same with the node-record encoding chosen: 1 = v1 (reference: indices as f32 values, exact below
+ * 2^24 nodes), 2 = v2 (u32 bit-casts in the same slots, leaf flag = bit 31 of B, low bits = count). */
+void orc_build_lbvh_enc(const float* pos, uint32_t n_vert, const float* nor, uint32_t n_nor,
+                        const uint32_t* vidx, const uint32_t* nidx, uint32_t n_tri,
+                        float* nodes, float* tri_pos, float* tri_nor,
+                        uint32_t* codes, uint32_t* order, double* seconds, int encoding);
 
 /* web/script.js:30-154,591-612,880-929: the 44 uniform floats.
  * sliders = {scaleX,scaleY,scaleZ, rotX,rotY,rotZ (degrees), posX,posY,posZ} */

@@ -10,7 +10,8 @@ import ctypes as C
 import numpy as np
 
 from . import _abi
-from ._abi import (FLAG_COUNT_WORK, LAYOUT_AOS32, LAYOUT_WIDE64, MODE_PRIMARY, MODE_PT, MODE_SHADOW)  # noqa: F401
+from ._abi import (FLAG_COUNT_WORK, LAYOUT_AOS32, LAYOUT_WIDE64, MODE_PRIMARY, MODE_PT, MODE_SHADOW,  # noqa: F401
+                   NODES_V1, NODES_V2)
 
 _L = _abi.load()          # raises ImportError when the HIP extension is not built
 
@@ -158,6 +159,13 @@ class Context:
     def set_mesh(self, mesh):
         self._chk(_L.rt_set_mesh(self._h, _vp(mesh.positions), mesh.positions.shape[0], _vp(mesh.normals),
                                  mesh.normals.shape[0], _vp(mesh.vert_idx), _vp(mesh.norm_idx), mesh.n_tri))
+
+    def set_node_encoding(self, encoding):
+        """NODES_V1 (reference, f32-valued indices, < 2^24 nodes) or NODES_V2 (u32 bit-casts) for the next build / import."""
+        self._chk(_L.rt_set_node_encoding(self._h, encoding))
+
+    def node_encoding(self):
+        return int(_L.rt_get_node_encoding(self._h))
 
     def build_lbvh(self):
         st = _abi.BuildStats()

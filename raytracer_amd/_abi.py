@@ -13,6 +13,7 @@ RT_OK, RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_IO, RT_ERR_LIMIT, RT
 MODE_PRIMARY, MODE_SHADOW, MODE_PT = 0, 1, 2
 LAYOUT_WIDE64, LAYOUT_AOS32 = 0, 1
 FLAG_COUNT_WORK = 1
+NODES_V1, NODES_V2 = 1, 2
 
 # every symbol include/rtcore.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
@@ -23,7 +24,7 @@ SYMBOLS = [
     "rt_get_nodes", "rt_get_triangles", "rt_set_bvh", "rt_save_bvh", "rt_load_bvh",
     "rt_render_opts_default", "rt_render", "rt_render_device", "rt_packed_rows", "rt_deinterleave_device",
     "rt_bvh_view_get", "rt_bvh_export_device", "rt_bvh_adopt_device", "rt_synchronize", "rt_stream",
-    "rt_profile_begin", "rt_profile_end",
+    "rt_profile_begin", "rt_profile_end", "rt_set_node_encoding", "rt_get_node_encoding",
 ]
 
 
@@ -135,6 +136,8 @@ def load():
         "rt_bvh_adopt_device": (C.c_int, [vp, C.POINTER(BvhView)]),
         "rt_synchronize": (C.c_int, [vp]),
         "rt_stream": (vp, [vp]),
+        "rt_set_node_encoding": (C.c_int, [vp, C.c_int]),
+        "rt_get_node_encoding": (C.c_int, [vp]),
         "rt_profile_begin": (C.c_int, [vp]),
         "rt_profile_end": (C.c_int, [vp, vp, vp, vp]),
     }

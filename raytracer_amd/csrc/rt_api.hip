@@ -61,6 +61,7 @@ struct rt_ctx {
   DevBuf<float> own_nodes, own_tri_pos, own_tri_nor;
   DevBuf<float4> wide, tri_pre;
   bool have_bvh = false;
+  int node_encoding = RT_NODES_V1;   // encoding of the next built / imported / adopted node buffer
 
   // render scratch
   DevBuf<uint32_t> r_tile_counter, r_list;
@@ -89,9 +90,23 @@ struct DeviceGuard {   // makes the context's device current for the duration of
   ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
+// limits of the two node-record encodings
+int check_encoding_limits(rt_ctx* ctx, const char* who, uint64_t n_nodes, uint64_t n_tri) {
+  if (ctx->node_encoding == RT_NODES_V1 && n_nodes > (1ull << 24))
+    return ctx->fail(RT_ERR_LIMIT, std::string(who) + ": v1 node records store indices as f32 values, exact only below 2^24 nodes "
+                                   "(SURVEY F11); select RT_NODES_V2 with rt_set_node_encoding");
+  if (n_tri > (1ull << 28) || n_nodes > (1ull << 29))
+    return ctx->fail(RT_ERR_LIMIT, std::string(who) + ": more than 2^28 triangles");
+  return RT_OK;
+}
+
 int finish_bvh(rt_ctx* ctx) {   // derive the traversal layout from the interchange buffers
   RtBvhDev& b = ctx->bvh;
+  b.v2 = ctx->node_encoding == RT_NODES_V2;
+  // WIDE64 leaf ref = start | (count-1) << leaf_shift in 31 bits: 23 keeps counts up to 256 for scenes below
+  // 2^23 triangles; larger scenes give the start more bits (count bits = 31 - leaf_shift)
   b.leaf_shift = 23;
+  while (b.leaf_shift < 31 && ((uint64_t)b.n_tri > (1ull << b.leaf_shift))) b.leaf_shift += 1;
   b.n_wide = b.n_nodes;   // imported trees may number internal nodes anywhere in [0, N)
   HIPCHK(ctx->wide.ensure((size_t)b.n_wide * 4));
   HIPCHK(ctx->tri_pre.ensure((size_t)b.n_tri * 3));
@@ -104,7 +119,9 @@ int finish_bvh(rt_ctx* ctx) {   // derive the traversal layout from the intercha
   HIPCHK(hipMemcpyAsync(w, ctx->words.p, sizeof(w), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemcpyAsync(b.root_box, b.nodes, sizeof(b.root_box), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (w[1] & 2u) return ctx->fail(RT_ERR_LIMIT, "leaf start/count exceeds the WIDE64 reference encoding (start < 2^23, count <= 256)");
+  if (w[1] & 2u)
+    return ctx->fail(RT_ERR_LIMIT, "a leaf's start/count does not fit the WIDE64 leaf reference (start < 2^" + std::to_string(b.leaf_shift) +
+                                   ", count <= " + std::to_string(b.leaf_shift >= 31 ? 1u : (1u << (31 - b.leaf_shift))) + ")");
   if (w[1] & 4u) return ctx->fail(RT_ERR_INVALID, "node buffer has an out-of-range child index");
   b.root_ref = w[0];
   ctx->have_bvh = true;
@@ -170,6 +187,14 @@ extern "C" int rt_synchronize(rt_ctx* ctx) {
 extern "C" void* rt_stream(rt_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 // ================================================================ hot path 1
+extern "C" int rt_set_node_encoding(rt_ctx* ctx, int encoding) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (encoding != RT_NODES_V1 && encoding != RT_NODES_V2) return ctx->fail(RT_ERR_INVALID, "rt_set_node_encoding: unknown encoding");
+  ctx->node_encoding = encoding;
+  return RT_OK;
+}
+extern "C" int rt_get_node_encoding(rt_ctx* ctx) { return ctx ? (ctx->have_bvh ? (ctx->bvh.v2 ? RT_NODES_V2 : RT_NODES_V1) : ctx->node_encoding) : RT_ERR_INVALID; }
+
 extern "C" int rt_set_mesh(rt_ctx* ctx, const float* positions, uint32_t n_vert, const float* normals, uint32_t n_nor,
                            const uint32_t* vert_idx, const uint32_t* nor_idx, uint32_t n_tri) {
   if (!ctx) return RT_ERR_INVALID;
@@ -197,8 +222,8 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
   if (!ctx) return RT_ERR_INVALID;
   if (ctx->n_tri_mesh == 0) return ctx->fail(RT_ERR_INVALID, "rt_build_lbvh: call rt_set_mesh first");
   const uint32_t T = ctx->n_tri_mesh, N = 2 * T - 1;
-  if (N > (1u << 24))
-    return ctx->fail(RT_ERR_LIMIT, "rt_build_lbvh: v1 node records store indices as f32 values, exact only below 2^24 (SURVEY F11)");
+  { const int lrc = check_encoding_limits(ctx, "rt_build_lbvh", N, T); if (lrc != RT_OK) return lrc; }
+  const bool v2 = ctx->node_encoding == RT_NODES_V2;
   DeviceGuard g(ctx->device);
   hipStream_t s = ctx->stream;
   HIPCHK(ctx->bounds_enc.ensure(8)); HIPCHK(ctx->bounds_f.ensure(8));
@@ -229,7 +254,7 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
   HIPCHK(hipEventRecord(ctx->ev[3], s));
   rt_launch_karras(b, s);
   HIPCHK(hipEventRecord(ctx->ev[4], s));
-  rt_launch_refit(b, ctx->own_nodes.p, ctx->own_tri_pos.p, ctx->own_tri_nor.p, /*fenced=*/false, s);
+  rt_launch_refit(b, ctx->own_nodes.p, ctx->own_tri_pos.p, ctx->own_tri_nor.p, /*fenced=*/false, v2, s);
   HIPCHK(hipEventRecord(ctx->ev[5], s));
   HIPCHK(hipGetLastError());
   uint32_t errw = 0;
@@ -239,7 +264,7 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
   if (errw & 8u) {   // the write-through hand-off was caught stale by k_refit_verify: redo with full fences
     ctx->refit_fallbacks += 1;
     HIPCHK(hipMemsetAsync(ctx->words.p + 2, 0, sizeof(uint32_t), s));
-    rt_launch_refit(b, ctx->own_nodes.p, ctx->own_tri_pos.p, ctx->own_tri_nor.p, /*fenced=*/true, s);
+    rt_launch_refit(b, ctx->own_nodes.p, ctx->own_tri_pos.p, ctx->own_tri_nor.p, /*fenced=*/true, v2, s);
     HIPCHK(hipEventRecord(ctx->ev[5], s));
     HIPCHK(hipMemcpyAsync(&errw, ctx->words.p + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -315,8 +340,22 @@ extern "C" int rt_get_triangles(rt_ctx* ctx, float* tri_pos, float* tri_nor) {
 }
 
 namespace {
-// host-side structural validation of an imported v1 node buffer: a bad index would fault the GPU
+// host-side structural validation of an imported node buffer: a bad index would fault the GPU
 int validate_nodes(rt_ctx* ctx, const float* nodes, uint32_t n_nodes, uint32_t n_tri) {
+  if (ctx->node_encoding == RT_NODES_V2) {
+    for (uint32_t i = 0; i < n_nodes; ++i) {
+      uint32_t A, B;
+      std::memcpy(&A, nodes + 8 * (size_t)i + 3, 4); std::memcpy(&B, nodes + 8 * (size_t)i + 7, 4);
+      if (B >> 31) {
+        const uint64_t cnt = B & 0x7FFFFFFFu;
+        if (cnt == 0 || (uint64_t)A + cnt > n_tri)
+          return ctx->fail(RT_ERR_INVALID, "imported BVH (v2): leaf range outside the triangle buffer at node " + std::to_string(i));
+      } else if (A >= n_nodes || B >= n_nodes) {
+        return ctx->fail(RT_ERR_INVALID, "imported BVH (v2): child index out of range at node " + std::to_string(i));
+      }
+    }
+    return RT_OK;
+  }
   for (uint32_t i = 0; i < n_nodes; ++i) {
     const float a = nodes[8 * (size_t)i + 3], b = nodes[8 * (size_t)i + 7];
     if (b < 0.0f) {
@@ -335,8 +374,9 @@ int validate_nodes(rt_ctx* ctx, const float* nodes, uint32_t n_nodes, uint32_t n
 extern "C" int rt_set_bvh(rt_ctx* ctx, const float* nodes, uint32_t n_nodes, const float* tri_pos, const float* tri_nor, uint32_t n_tri) {
   if (!ctx) return RT_ERR_INVALID;
   if (!nodes || !tri_pos || !tri_nor || n_nodes == 0 || n_tri == 0) return ctx->fail(RT_ERR_INVALID, "rt_set_bvh: empty input");
-  if (n_nodes > (1u << 24)) return ctx->fail(RT_ERR_LIMIT, "rt_set_bvh: v1 node records are exact only below 2^24 nodes (SURVEY F11)");
-  int rc = validate_nodes(ctx, nodes, n_nodes, n_tri);
+  int rc = check_encoding_limits(ctx, "rt_set_bvh", n_nodes, n_tri);
+  if (rc != RT_OK) return rc;
+  rc = validate_nodes(ctx, nodes, n_nodes, n_tri);
   if (rc != RT_OK) return rc;
   DeviceGuard g(ctx->device);
   ctx->have_bvh = false; ctx->built = false;
@@ -418,7 +458,7 @@ extern "C" int rt_bvh_adopt_device(rt_ctx* ctx, const rt_bvh_view* v) {
     return ctx->fail(RT_ERR_INVALID, "rt_bvh_adopt_device: incomplete view");
   if (v->nodes_bytes < 32ull * v->n_nodes || v->tri_pos_bytes < 48ull * v->n_tri || v->tri_nor_bytes < 48ull * v->n_tri)
     return ctx->fail(RT_ERR_INVALID, "rt_bvh_adopt_device: buffers smaller than the counts imply");
-  if (v->n_nodes > (1u << 24)) return ctx->fail(RT_ERR_LIMIT, "v1 node records are exact only below 2^24 nodes (SURVEY F11)");
+  { const int lrc = check_encoding_limits(ctx, "rt_bvh_adopt_device", v->n_nodes, v->n_tri); if (lrc != RT_OK) return lrc; }
   DeviceGuard g(ctx->device);
   ctx->have_bvh = false; ctx->built = false;
   ctx->bvh = RtBvhDev();
@@ -478,6 +518,7 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
   std::memset(&p, 0, sizeof(p));
   p.nodes = ctx->bvh.nodes; p.tri_pos = ctx->bvh.tri_pos; p.tri_nor = ctx->bvh.tri_nor;
   p.wide = ctx->bvh.wide; p.tri_pre = ctx->bvh.tri_pre; p.root_ref = ctx->bvh.root_ref; p.leaf_shift = ctx->bvh.leaf_shift;
+  p.nodes_v2 = ctx->bvh.v2 ? 1 : 0;
   p.step_budget = ctx->bvh.n_nodes + 64u;
   std::memcpy(p.U, uniforms, sizeof(float) * 44);
   p.mode = opts->mode; p.gi_samples = opts->gi_samples; p.gi_bounces = opts->gi_bounces; p.soft_samples = opts->soft_samples;

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(BLK) void k_karras(const uint32_t* __restrict__ k, 
   // node ids: internal k -> k, leaf k -> (T-1)+k
   const int c0 = (lo == gamma) ? (n - 1) + gamma : gamma;
   const int c1 = (hi == gamma + 1) ? (n - 1) + gamma + 1 : gamma + 1;
-  child[2 * i + 0] = c0; child[2 * i + 1] = c1;
+  child[2 * (size_t)i + 0] = c0; child[2 * (size_t)i + 1] = c1;
   parent[c0] = i; parent[c1] = i;
 }
 
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(BLK) void k_refit(const float* __restrict__ pos, co
                                                const uint32_t* __restrict__ order, uint32_t n_tri,
                                                const int32_t* __restrict__ child, const int32_t* __restrict__ parent,
                                                uint32_t* visit, float* nodes, float* __restrict__ tri_pos,
-                                               float* __restrict__ tri_nor) {
+                                               float* __restrict__ tri_nor, bool v2) {
   const uint32_t j = blockIdx.x * BLK + threadIdx.x;
   if (j >= n_tri) return;
   const uint32_t ti = order[j];
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(BLK) void k_refit(const float* __restrict__ pos, co
   V3 mn = v3(fminf(fminf(p[0].x, p[1].x), p[2].x), fminf(fminf(p[0].y, p[1].y), p[2].y), fminf(fminf(p[0].z, p[1].z), p[2].z));
   V3 mx = v3(fmaxf(fmaxf(p[0].x, p[1].x), p[2].x), fmaxf(fmaxf(p[0].y, p[1].y), p[2].y), fmaxf(fmaxf(p[0].z, p[1].z), p[2].z));
   int cur = (int)(n_tri - 1) + (int)j;
-  store_node<FENCED>(nodes, cur, mn, (float)j, mx, -1.0f);   // A = tri_start, B = -count (script.js:348,554,558)
+  store_node<FENCED>(nodes, cur, mn, enc_index(v2, j), mx, enc_leaf_b(v2, 1u));   // A = tri_start, B = -count (script.js:348,554,558)
   for (;;) {
     const int par = parent[cur];
     if (par < 0) break;
@@ -378,13 +378,13 @@ __global__ __launch_bounds__(BLK) void k_refit(const float* __restrict__ pos, co
     const uint32_t arrived = atomicAdd(&visit[par], 1u);
     if (arrived == 0) break;                           // the sibling's thread will finish this node
     if (FENCED) __threadfence();                       // acquire the sibling's record
-    const int c0 = child[2 * par + 0], c1 = child[2 * par + 1];
+    const int c0 = child[2 * (size_t)par + 0], c1 = child[2 * (size_t)par + 1];
     const int sib = (c0 == cur) ? c1 : c0;
     V3 smn, smx;
     load_box<FENCED>(nodes, sib, smn, smx);
     mn = v3(fminf(mn.x, smn.x), fminf(mn.y, smn.y), fminf(mn.z, smn.z));
     mx = v3(fmaxf(mx.x, smx.x), fmaxf(mx.y, smx.y), fmaxf(mx.z, smx.z));
-    store_node<FENCED>(nodes, par, mn, (float)c0, mx, (float)c1);   // indices as f32 values (F11)
+    store_node<FENCED>(nodes, par, mn, enc_index(v2, (uint32_t)c0), mx, enc_index(v2, (uint32_t)c1));   // v1: indices as f32 values (F11)
     cur = par;
   }
 }
@@ -392,23 +392,23 @@ __global__ __launch_bounds__(BLK) void k_refit(const float* __restrict__ pos, co
 // every internal box must equal the union of its children's boxes, every slot must be filled
 __global__ __launch_bounds__(BLK) void k_refit_verify(const float* __restrict__ nodes, uint32_t n_tri,
                                                       const int32_t* __restrict__ child, const uint32_t* __restrict__ visit,
-                                                      uint32_t* err) {
+                                                      uint32_t* err, bool v2) {
   const uint32_t i = blockIdx.x * BLK + threadIdx.x;
   if (i + 1 >= n_tri) return;
   const float4* nd = reinterpret_cast<const float4*>(nodes);
-  const int c0 = child[2 * i + 0], c1 = child[2 * i + 1];
+  const int c0 = child[2 * (size_t)i + 0], c1 = child[2 * (size_t)i + 1];
   const float4 a = nd[2 * (size_t)i], b = nd[2 * (size_t)i + 1];
   const float4 a0 = nd[2 * (size_t)c0], b0 = nd[2 * (size_t)c0 + 1], a1 = nd[2 * (size_t)c1], b1 = nd[2 * (size_t)c1 + 1];
-  bool ok = (visit[i] == 2u) && (a.w == (float)c0) && (b.w == (float)c1);
+  bool ok = (visit[i] == 2u) && !dec_is_leaf(v2, b.w) && (dec_index(v2, a.w) == c0) && (dec_index(v2, b.w) == c1);
   ok = ok && a.x == fminf(a0.x, a1.x) && a.y == fminf(a0.y, a1.y) && a.z == fminf(a0.z, a1.z);
   ok = ok && b.x == fmaxf(b0.x, b1.x) && b.y == fmaxf(b0.y, b1.y) && b.z == fmaxf(b0.z, b1.z);
   if (!ok) atomicOr(err, 8u);
 }
 
 // ---------------------------------------------------------------- traversal layout
-RT_DEV uint32_t make_ref(const float4 a, const float4 b, int node, int leaf_shift, uint32_t* err) {
-  if (b.w < 0.0f) {                                   // leaf test of fetchCachedNode, compute.wgsl:75
-    const uint32_t start = (uint32_t)sat_i32(a.w), count = (uint32_t)(-sat_i32(b.w));
+RT_DEV uint32_t make_ref(const float4 a, const float4 b, int node, int leaf_shift, bool v2, uint32_t* err) {
+  if (dec_is_leaf(v2, b.w)) {                         // leaf test of fetchCachedNode, compute.wgsl:75
+    const uint32_t start = (uint32_t)dec_index(v2, a.w), count = (uint32_t)dec_count(v2, b.w);
     const uint32_t max_start = (leaf_shift >= 31) ? 0x7FFFFFFFu : ((1u << leaf_shift) - 1u);
     const uint32_t max_count = (leaf_shift >= 31) ? 1u : (1u << (31 - leaf_shift));
     if (start > max_start || count < 1 || count > max_count) { atomicOr(err, 2u); return 0xFFFFFFFFu; }
@@ -418,18 +418,18 @@ RT_DEV uint32_t make_ref(const float4 a, const float4 b, int node, int leaf_shif
 }
 
 __global__ __launch_bounds__(BLK) void k_pack_wide(const float* __restrict__ nodes, uint32_t n_nodes, float4* __restrict__ wide,
-                                                   uint32_t n_wide, int leaf_shift, uint32_t* root_ref, uint32_t* err) {
+                                                   uint32_t n_wide, int leaf_shift, bool v2, uint32_t* root_ref, uint32_t* err) {
   const uint32_t i = blockIdx.x * BLK + threadIdx.x;
   if (i >= n_nodes) return;
   const float4* nd = reinterpret_cast<const float4*>(nodes);
   const float4 a = nd[2 * (size_t)i], b = nd[2 * (size_t)i + 1];
-  if (i == 0) *root_ref = make_ref(a, b, 0, leaf_shift, err);
-  if (b.w < 0.0f) return;
-  const int c0 = sat_i32(a.w), c1 = sat_i32(b.w);
+  if (i == 0) *root_ref = make_ref(a, b, 0, leaf_shift, v2, err);
+  if (dec_is_leaf(v2, b.w)) return;
+  const int c0 = dec_index(v2, a.w), c1 = dec_index(v2, b.w);
   if (i >= n_wide || c0 < 0 || c1 < 0 || (uint32_t)c0 >= n_nodes || (uint32_t)c1 >= n_nodes) { atomicOr(err, 4u); return; }
   const float4 a0 = nd[2 * (size_t)c0], b0 = nd[2 * (size_t)c0 + 1];
   const float4 a1 = nd[2 * (size_t)c1], b1 = nd[2 * (size_t)c1 + 1];
-  const uint32_t r0 = make_ref(a0, b0, c0, leaf_shift, err), r1 = make_ref(a1, b1, c1, leaf_shift, err);
+  const uint32_t r0 = make_ref(a0, b0, c0, leaf_shift, v2, err), r1 = make_ref(a1, b1, c1, leaf_shift, v2, err);
   wide[4 * (size_t)i + 0] = make_float4(a0.x, a0.y, a0.z, __uint_as_float(r0));
   wide[4 * (size_t)i + 1] = make_float4(b0.x, b0.y, b0.z, __uint_as_float(r1));
   wide[4 * (size_t)i + 2] = make_float4(a1.x, a1.y, a1.z, 0.0f);
@@ -486,22 +486,22 @@ void rt_launch_karras(const RtBuildBuffers& b, hipStream_t s) {
   hipLaunchKernelGGL(k_karras, dim3((n_int + BLK - 1) / BLK), dim3(BLK), 0, s, b.keys_a, b.n_tri, b.child, b.parent);
 }
 
-void rt_launch_refit(const RtBuildBuffers& b, float* nodes, float* tri_pos, float* tri_nor, bool fenced, hipStream_t s) {
+void rt_launch_refit(const RtBuildBuffers& b, float* nodes, float* tri_pos, float* tri_nor, bool fenced, bool v2, hipStream_t s) {
   if (b.n_tri > 1) (void)hipMemsetAsync(b.visit, 0, sizeof(uint32_t) * (b.n_tri - 1), s);
   const dim3 g((b.n_tri + BLK - 1) / BLK), blk(BLK);
   if (fenced)
     hipLaunchKernelGGL(k_refit<true>, g, blk, 0, s, b.pos, b.nor, b.vidx, b.nidx, b.vals_a, b.n_tri, b.child, b.parent, b.visit,
-                       nodes, tri_pos, tri_nor);
+                       nodes, tri_pos, tri_nor, v2);
   else
     hipLaunchKernelGGL(k_refit<false>, g, blk, 0, s, b.pos, b.nor, b.vidx, b.nidx, b.vals_a, b.n_tri, b.child, b.parent, b.visit,
-                       nodes, tri_pos, tri_nor);
+                       nodes, tri_pos, tri_nor, v2);
   if (b.n_tri > 1)   // sets bit 8 of err_flag on any inconsistency
-    hipLaunchKernelGGL(k_refit_verify, dim3((b.n_tri - 1 + BLK - 1) / BLK), blk, 0, s, nodes, b.n_tri, b.child, b.visit, b.err_flag);
+    hipLaunchKernelGGL(k_refit_verify, dim3((b.n_tri - 1 + BLK - 1) / BLK), blk, 0, s, nodes, b.n_tri, b.child, b.visit, b.err_flag, v2);
 }
 
 // root_ref / err words live right behind the bounds words: see rt_api.hip (scratch[0], scratch[1])
 void rt_launch_pack_impl(const RtBvhDev& bvh, uint32_t* d_root_ref, uint32_t* d_err, hipStream_t s) {
   hipLaunchKernelGGL(k_pack_wide, dim3((bvh.n_nodes + BLK - 1) / BLK), dim3(BLK), 0, s, bvh.nodes, bvh.n_nodes, bvh.wide,
-                     bvh.n_wide, bvh.leaf_shift, d_root_ref, d_err);
+                     bvh.n_wide, bvh.leaf_shift, bvh.v2, d_root_ref, d_err);
   hipLaunchKernelGGL(k_pack_tris, dim3((bvh.n_tri + BLK - 1) / BLK), dim3(BLK), 0, s, bvh.tri_pos, bvh.n_tri, bvh.tri_pre);
 }

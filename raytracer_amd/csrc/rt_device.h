@@ -39,6 +39,15 @@ RT_DEV int32_t sat_i32(float f) {
   return (int32_t)f;
 }
 
+// Slots A / B of the 32-byte node record (rt_internal.h): v1 = indices as f32 VALUES, leaf B = -count
+// (web/script.js:546-559, exact below 2^24, F11); v2 = u32 bit-casts in the same slots, leaf flag =
+// bit 31 of B, low 31 bits = count.  The floats are only ever moved, never computed on.
+RT_DEV float enc_index(bool v2, uint32_t i) { return v2 ? __uint_as_float(i) : (float)i; }
+RT_DEV float enc_leaf_b(bool v2, uint32_t count) { return v2 ? __uint_as_float(0x80000000u | count) : -(float)count; }
+RT_DEV bool dec_is_leaf(bool v2, float b) { return v2 ? ((__float_as_uint(b) >> 31) != 0u) : (b < 0.0f); }
+RT_DEV int32_t dec_index(bool v2, float a) { return v2 ? (int32_t)__float_as_uint(a) : sat_i32(a); }
+RT_DEV int32_t dec_count(bool v2, float b) { return v2 ? (int32_t)(__float_as_uint(b) & 0x7FFFFFFFu) : -sat_i32(b); }
+
 // web/morton_compute.wgsl:18-31
 RT_DEV uint32_t expand_bits(uint32_t v) {
   uint32_t x = v & 0x3FFu;

@@ -10,7 +10,7 @@
 
 // ---------------------------------------------------------------- device memory layout (HBM)
 // Interchange (public, web/script.js:526-561):
-//   nodes    f32[8N]   32 B/node  {mn.xyz, A | mx.xyz, B}
+//   nodes    f32[8N]   32 B/node  {mn.xyz, A | mx.xyz, B}   (A/B: v1 f32 values or v2 u32 bit-casts, rt_device.h)
 //   tri_pos  f32[12T]  48 B/tri   3 x (x,y,z,0)
 //   tri_nor  f32[12T]  48 B/tri
 // Traversal layout (internal, derived by rt_pack_*):
@@ -31,6 +31,7 @@ struct RtBvhDev {
   uint32_t n_nodes = 0, n_tri = 0, n_wide = 0;
   uint32_t root_ref = 0;     // traversal ref of node 0
   int      leaf_shift = 23;
+  bool     v2 = false;       // node record encoding of `nodes` (RT_NODES_V2)
   bool     owns_interchange = true;
   float    root_box[8] = {};   // host copy of node 0 (mn.xyz, A | mx.xyz, B) for the screen-space cull rectangle
 };
@@ -43,6 +44,7 @@ struct RtRenderParams {
   const float4* tri_pre;
   uint32_t root_ref;
   int      leaf_shift;
+  int      nodes_v2;               // encoding of `nodes` (read by the AOS32 walk only)
   uint32_t step_budget;            // n_nodes + 64
   float    U[44];
   int mode, gi_samples, gi_bounces, soft_samples, max_stack;
@@ -89,7 +91,7 @@ void rt_launch_bounds(const RtBuildBuffers& b, hipStream_t s);
 void rt_launch_morton(const RtBuildBuffers& b, hipStream_t s);
 void rt_launch_sort(const RtBuildBuffers& b, hipStream_t s);      // result in keys_a / vals_a
 void rt_launch_karras(const RtBuildBuffers& b, hipStream_t s);
-void rt_launch_refit(const RtBuildBuffers& b, float* nodes, float* tri_pos, float* tri_nor, bool fenced, hipStream_t s);
+void rt_launch_refit(const RtBuildBuffers& b, float* nodes, float* tri_pos, float* tri_nor, bool fenced, bool v2, hipStream_t s);
 // derive the traversal layout from the interchange buffers; writes the root ref / error bits
 void rt_launch_pack_impl(const RtBvhDev& bvh, uint32_t* d_root_ref, uint32_t* d_err, hipStream_t s);
 

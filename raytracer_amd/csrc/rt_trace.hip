@@ -36,6 +36,7 @@ struct Scene {
   const float4* tri_pre;
   uint32_t root_ref;
   int leaf_shift;
+  bool v2;                 // encoding of `nodes`
   int max_stack;
   uint32_t step_budget;    // > number of nodes: a valid tree never exhausts it; a cyclic (corrupt) import cannot hang the GPU
   uint32_t* stk_ref;       // this thread's LDS column, stride TBLK
@@ -171,9 +172,9 @@ RT_DEV NodeRec fetch_node(const Scene& S, int idx) {   // compute.wgsl:68-88
   const float4 a = S.nodes[2 * (size_t)(uint32_t)idx], b = S.nodes[2 * (size_t)(uint32_t)idx + 1];
   NodeRec n;
   n.mn = xyz(a); n.mx = xyz(b);
-  n.leaf = (b.w < 0.0f);
-  if (n.leaf) { n.start = sat_i32(a.w); n.count = -sat_i32(b.w); n.c0 = -1; n.c1 = -1; }
-  else { n.c0 = sat_i32(a.w); n.c1 = sat_i32(b.w); n.start = -1; n.count = 0; }
+  n.leaf = dec_is_leaf(S.v2, b.w);
+  if (n.leaf) { n.start = dec_index(S.v2, a.w); n.count = dec_count(S.v2, b.w); n.c0 = -1; n.c1 = -1; }
+  else { n.c0 = dec_index(S.v2, a.w); n.c1 = dec_index(S.v2, b.w); n.start = -1; n.count = 0; }
   return n;
 }
 
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
   S.tri_pos = reinterpret_cast<const float4*>(p.tri_pos);
   S.tri_nor = reinterpret_cast<const float4*>(p.tri_nor);
   S.wide = p.wide; S.tri_pre = p.tri_pre;
-  S.root_ref = p.root_ref; S.leaf_shift = p.leaf_shift; S.max_stack = p.max_stack; S.step_budget = p.step_budget;
+  S.root_ref = p.root_ref; S.leaf_shift = p.leaf_shift; S.v2 = p.nodes_v2 != 0; S.max_stack = p.max_stack; S.step_budget = p.step_budget;
   S.stk_ref = stk_ref + threadIdx.x; S.stk_t = stk_t + threadIdx.x;
   Shade sh; sh.mode = p.mode; sh.gi_samples = p.gi_samples; sh.gi_bounces = p.gi_bounces; sh.soft_samples = p.soft_samples;
 
