@@ -38,6 +38,9 @@ def scene_mesh(name):
         m = scenes.s1m()
     elif name == "s70k":
         m = scenes.s70k()
+    elif name.startswith("lattice"):
+        # cfg 5 of SURVEY §8d: K copies of the (normalised) cfg-3 mesh on a lattice, flattened, normalised again
+        m = scenes.lattice(rt.normalize_mesh(scenes.s1m()), int(name[len("lattice"):]))
     else:
         raise SystemExit(f"unknown scene {name}")
     return rt.normalize_mesh(m)          # script.js:720: every mesh is normalised into the unit cube
@@ -54,6 +57,8 @@ def main():
     ap.add_argument("--mode", default="shadow", choices=["primary", "shadow", "pt"])
     ap.add_argument("--spp", type=int, default=32)
     ap.add_argument("--layout", default="wide64", choices=["wide64", "aos32"])
+    ap.add_argument("--encoding", default="auto", choices=["auto", "v1", "v2"],
+                    help="node records: v1 = reference (f32-valued indices, < 2^24 nodes), v2 = u32 bit-casts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
     args = ap.parse_args()
@@ -86,8 +91,12 @@ def main():
     # ---- hot path 1: build once on rank 0 (timed separately), replicate with RCCL
     build = None
     mesh = None
+    encoding = rt.NODES_V1
     if rank == 0:
         mesh = scene_mesh(args.scene)
+        if args.encoding == "v2" or (args.encoding == "auto" and 2 * mesh.n_tri - 1 > (1 << 24)):
+            encoding = rt.NODES_V2
+        ctx.set_node_encoding(encoding)
         ctx.set_mesh(mesh)
         runs = [ctx.build_lbvh() for _ in range(5)]
         runs.sort(key=lambda s: s["ms_total"])
@@ -153,13 +162,17 @@ def main():
         achieved = my_bytes / (trav_ms * 1e-3) / 1e9 if trav_ms > 0 else 0.0
         what = {"primary": "primary rays only", "shadow": "primary + 4 soft shadow rays",
                 "pt": f"full computeLighting_optimized: GI {args.spp} spp x 3 bounces + 4 soft shadow rays per vertex"}[args.mode]
+        scene_txt = {"s1m": "cfg3: S1M closed-form icosphere stand-in for dragon.obj",
+                     "s70k": "cfg1-2: S70k closed-form icosphere stand-in for bunny.obj"}.get(
+                         args.scene, f"cfg5: {args.scene[7:]} copies of S1M on a lattice, flattened")
         out = {
-            "metric": "Mrays/s primary+shadow, dragon.obj 4K" if args.mode == "shadow" else f"Mrays/s {args.mode}",
+            "metric": "Mrays/s primary+shadow, dragon.obj 4K" if (args.mode == "shadow" and args.scene == "s1m" and (W, H) == (3840, 2160))
+                      else f"Mrays/s {args.mode} {args.scene} {W}x{H}",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"cfg3: {args.scene.upper()} stand-in for dragon.obj ({build['n_tri']} triangles, closed-form "
-                                   f"icosphere), {W}x{H}, {what}, camera B (0,0,1.3), layout {args.layout}",
+            "config": {"workload": f"{scene_txt} ({build['n_tri']} triangles), {W}x{H}, {what}, camera B (0,0,1.3), "
+                                   f"layout {args.layout}, node records {'v2' if encoding == rt.NODES_V2 else 'v1'}",
                        "mode": args.mode, "rays_per_frame": int(total_rays), "stripes": "16-row round-robin" if world > 1 else "none"},
             "lbvh_build_ms": {k: round(float(v), 4) for k, v in build.items() if k.startswith("ms_")},
             "lbvh_build_roofline_frac": round(build["algorithmic_bytes"] / (build["ms_total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
@@ -199,11 +212,12 @@ def cpu_baseline(args, mesh, U, mode):
     every k-th row of the 4K image, k chosen so that the sample takes ~10-30 s of CPU time."""
     from oracle import binding as oracle     # checker / baseline only — never on the product path
     cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count() or 1))
-    b = oracle.build_lbvh(mesh.positions, mesh.normals, mesh.vert_idx, mesh.norm_idx)
+    enc = 2 if 2 * mesh.n_tri - 1 > (1 << 24) or args.encoding == "v2" else 1
+    b = oracle.build_lbvh(mesh.positions, mesh.normals, mesh.vert_idx, mesh.norm_idx, encoding=enc)
     H = args.height
     # probe: 8 rows spread over the frame
     _, st = oracle.render(b["nodes"], b["tri_pos"], b["tri_nor"], U, mode=mode, gi_samples=args.spp, rows=(0, H, max(1, H // 8)),
-                          n_threads=cores, want=())
+                          n_threads=cores, want=(), encoding=enc)
     per_row = max(st["seconds"] / max(1, len(range(0, H, max(1, H // 8)))), 1e-6)
     n_rows = int(min(H, max(8, args.cpu_seconds / per_row)))
     step = max(1, H // n_rows)
@@ -213,7 +227,7 @@ def cpu_baseline(args, mesh, U, mode):
     reps = 0
     while reps < 2 or (secs * cores < args.cpu_seconds and reps < 64):
         _, st = oracle.render(b["nodes"], b["tri_pos"], b["tri_nor"], U, mode=mode, gi_samples=args.spp, rows=(0, H, step),
-                              n_threads=cores, want=())
+                              n_threads=cores, want=(), encoding=enc)
         rays += st["rays_primary"] + st["rays_shadow"] + st["rays_bounce"]
         secs += st["seconds"]
         reps += 1

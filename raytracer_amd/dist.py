@@ -63,12 +63,12 @@ class GpuBackend:
 def replicate_bvh(ctx, rank, world, device):
     """Broadcast rank 0's flat BVH (nodes, triPos, triNor) and adopt it on every other rank.
     Returns the tensors that back the adopted BVH (keep them alive)."""
-    meta = torch.zeros(2, dtype=torch.int64, device=device)
+    meta = torch.zeros(3, dtype=torch.int64, device=device)
     if rank == 0:
         T, N = ctx.counts()
-        meta[0], meta[1] = T, N
+        meta[0], meta[1], meta[2] = T, N, ctx.node_encoding()
     dist.broadcast(meta, 0)
-    T, N = int(meta[0]), int(meta[1])
+    T, N, enc = int(meta[0]), int(meta[1]), int(meta[2])
     bufs = [torch.empty(32 * N, dtype=torch.uint8, device=device), torch.empty(48 * T, dtype=torch.uint8, device=device),
             torch.empty(48 * T, dtype=torch.uint8, device=device)]
     if rank == 0:
@@ -78,6 +78,7 @@ def replicate_bvh(ctx, rank, world, device):
     if torch.device(device).type == "cuda":
         torch.cuda.synchronize(device)
     if rank != 0:
+        ctx.set_node_encoding(enc)          # v1 / v2 node records travel as the same 32-byte slots
         ctx.adopt_bvh_device(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), N, T)
     return bufs
 

@@ -45,7 +45,13 @@ class FakeCtx:
     """counts / export / adopt of the C ABI, on host memory."""
 
     def __init__(self, bvh=None):
-        self.bvh, self.adopted = bvh, None
+        self.bvh, self.adopted, self.enc = bvh, None, 1
+
+    def node_encoding(self):
+        return self.enc
+
+    def set_node_encoding(self, enc):
+        self.enc = enc
 
     def counts(self):
         return self.bvh["tri_pos"].shape[0], self.bvh["nodes"].shape[0]
