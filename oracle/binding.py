@@ -62,6 +62,9 @@ def lib():
                                      f32p, f32p, f32p, u32p, u32p, C.POINTER(C.c_double)]
         L.orc_build_lbvh_enc.restype = None
         L.orc_build_lbvh_enc.argtypes = L.orc_build_lbvh.argtypes + [C.c_int]
+        L.orc_build_sah.restype = C.c_int
+        L.orc_build_sah.argtypes = [f32p, f32p, u32p, u32p, C.c_uint32, C.c_int, f32p, C.c_uint32, C.POINTER(C.c_uint32),
+                                    f32p, f32p, u32p, C.POINTER(C.c_double)]
         L.orc_make_uniforms.restype = None
         L.orc_make_uniforms.argtypes = [C.POINTER(C.c_double), C.c_double, C.c_double, C.POINTER(C.c_double),
                                         C.c_uint32, C.c_uint32, C.c_float, f32p]
@@ -138,6 +141,23 @@ def build_lbvh(pos, nor, vidx, nidx, encoding=1):
     lib().orc_build_lbvh_enc(p, p.size // 3, n, n.size // 3, v, ni, T, nodes, tp, tn, codes, order, C.byref(sec), encoding)
     return dict(nodes=nodes.reshape(-1, 8), tri_pos=tp.reshape(T, 3, 4), tri_nor=tn.reshape(T, 3, 4),
                 codes=codes, order=order, seconds=sec.value)
+
+
+def build_sah(pos, nor, vidx, nidx, leaf=1):
+    """The reference's own builder (script.js:285-513 + flattenForSSBO).  Same dict as build_lbvh, without codes."""
+    p, v = _mesh(pos, vidx)
+    n, ni = _mesh(nor, nidx)
+    T = v.size // 3
+    cap = 2 * T
+    nodes = np.zeros(cap * 8, np.float32)
+    tp, tn = np.zeros(T * 12, np.float32), np.zeros(T * 12, np.float32)
+    order = np.zeros(T, np.uint32)
+    sec, nn = C.c_double(), C.c_uint32()
+    rc = lib().orc_build_sah(p, n, v, ni, T, leaf, nodes, cap, C.byref(nn), tp, tn, order, C.byref(sec))
+    if rc != 0:
+        raise RuntimeError(f"orc_build_sah failed: {rc}")
+    return dict(nodes=nodes[:nn.value * 8].reshape(-1, 8).copy(), tri_pos=tp.reshape(T, 3, 4), tri_nor=tn.reshape(T, 3, 4),
+                order=order, seconds=sec.value)
 
 
 DEFAULT_SLIDERS = (1.0, 1.0, 1.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0)

@@ -16,6 +16,7 @@
  *   web/compute.wgsl:68-446         fetchCachedNode … cs_main
  *   web/script.js:207-227           normalizeMesh
  *   web/script.js:526-561           flattenForSSBO (node + triangle buffer layout)
+ *   web/script.js:285-513           buildLBVH, the reference's CPU SAH builder (rt_oracle_sah.cpp)
  *   web/script.js:30-154,591-612,880-929   camera / TRS / invert4 / uniform packing
  * Sort / Karras radix tree / refit have no reference code; they follow
  * the definitions pinned there.
@@ -94,6 +95,15 @@ void orc_build_lbvh_enc(const float* pos, uint32_t n_vert, const float* nor, uin
                         const uint32_t* vidx, const uint32_t* nidx, uint32_t n_tri,
                         float* nodes, float* tri_pos, float* tri_nor,
                         uint32_t* codes, uint32_t* order, double* seconds, int encoding);
+
+/* The reference's ACTUAL builder: web/script.js:285-513 `buildLBVH` — a recursive 20-bin SAH builder
+ * over centroids with median fallback, DFS pre-order numbering — followed by flattenForSSBO (script.js:526-561).
+ * JS double arithmetic with Float32Array rounding points reproduced.  nodes: capacity nodes_capacity records of 8
+ * floats (v1 encoding; at leaf = 1 the tree has 2T-1 nodes).  Returns 0, -2 if capacity is too small (*n_nodes_out
+ * is still set), -11 where the reference would recurse forever (partition left one side empty), -12 on NaN input. */
+int orc_build_sah(const float* positions, const float* normals, const uint32_t* vertIdx, const uint32_t* normIdx,
+                  uint32_t n_tri, int leaf, float* nodes_out, uint32_t nodes_capacity, uint32_t* n_nodes_out,
+                  float* tri_pos, float* tri_nor, uint32_t* order_out, double* seconds);
 
 /* web/script.js:30-154,591-612,880-929: the 44 uniform floats.
  * sliders = {scaleX,scaleY,scaleZ, rotX,rotY,rotZ (degrees), posX,posY,posZ} */
