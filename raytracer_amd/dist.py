@@ -49,10 +49,19 @@ class GpuBackend:
         # the collective (torch's stream) must see the finished stripes (context stream)
         torch.cuda.current_stream(self.device).wait_stream(self.ext)
 
-    def deinterleave(self, gathered, image, width, height, world, rpr):
-        # the de-interleave kernel, and the next frame's render into `packed`, run on the context's stream
-        # after the collective on torch's stream
-        self.ext.wait_stream(torch.cuda.current_stream(self.device))
+    def after_gather(self):
+        """Event on torch's stream right behind the collective just queued."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return ev
+
+    def deinterleave(self, gathered, image, width, height, world, rpr, after=None):
+        # the de-interleave kernel runs on the context's stream once ITS frame's collective (torch's stream) is done;
+        # a later frame's collective may still be in flight
+        if after is not None:
+            self.ext.wait_event(after)
+        else:
+            self.ext.wait_stream(torch.cuda.current_stream(self.device))
         self.ctx.deinterleave_device(gathered.data_ptr(), image.data_ptr(), width, height, 4, STRIPE_ROWS, world, rpr)
 
     def finish(self):
@@ -84,7 +93,14 @@ def replicate_bvh(ctx, rank, world, device):
 
 
 class ShardedFrame:
-    """One frame sharded as image-space stripes over `world` ranks and gathered on every rank."""
+    """One frame sharded as image-space stripes over `world` ranks and gathered on every rank.
+
+    Asynchronous frame loops (step(want_stats=False)) are software-pipelined two deep: the context stream runs
+    render(i), de-interleave(i-1), render(i+1), ... while frame i's all-gather runs on torch's stream, so the
+    xGMI exchange of one frame overlaps the traversal of the next.  Two packed / gathered buffer pairs alternate;
+    render(i+2) reuses pair i only after de-interleave(i), which waited for all-gather(i)."""
+
+    DEPTH = 2
 
     def __init__(self, backend, width, height, rank, world, base_opts=None, force_collective=False):
         """force_collective: run the gather + de-interleave leg even at world == 1 (tests the stream plumbing on one GPU)."""
@@ -95,22 +111,43 @@ class ShardedFrame:
         self.opts = render_opts(mode=o.mode, gi_samples=o.gi_samples, gi_bounces=o.gi_bounces, soft_samples=o.soft_samples,
                                 max_stack=o.max_stack, layout=o.layout, flags=o.flags,
                                 stripe_rows=STRIPE_ROWS if world > 1 else 0, stripe_rank=rank, stripe_world=world)
-        self.packed = backend.alloc(self.rpr, width)
-        self.gathered = backend.alloc(self.rpr * world, width) if self.collective else None
+        depth = self.DEPTH if self.collective else 1
+        self.packed_ring = [backend.alloc(self.rpr, width) for _ in range(depth)]
+        self.gathered_ring = [backend.alloc(self.rpr * world, width) for _ in range(depth)] if self.collective else None
+        self.packed = self.packed_ring[0]
         self.image = backend.alloc(height, width) if self.collective else self.packed
+        self.n_steps = 0
+        self.pending = None            # (slot, event) of the frame whose all-gather is queued but not yet de-interleaved
+
+    def _drain(self):
+        if self.pending is not None:
+            slot, ev = self.pending
+            self.pending = None
+            if ev is not None:
+                self.b.deinterleave(self.gathered_ring[slot], self.image, self.w, self.h, self.world, self.rpr, after=ev)
+            else:
+                self.b.deinterleave(self.gathered_ring[slot], self.image, self.w, self.h, self.world, self.rpr)
 
     def step(self, U, want_stats=True):
         """Render my stripes, gather all stripes, de-interleave.  Returns this rank's render stats (or None).
-        With want_stats=False nothing synchronises with the host: call finish() before reading self.image."""
-        st = self.b.render_packed(U, self.opts, self.packed, want_stats) if not want_stats else \
-            self.b.render_packed(U, self.opts, self.packed)
+        With want_stats=False nothing synchronises with the host and the de-interleave of this frame is queued by the
+        NEXT step (or finish()): call finish() before reading self.image."""
+        slot = self.n_steps % len(self.packed_ring)
+        self.n_steps += 1
+        packed = self.packed_ring[slot]
+        st = self.b.render_packed(U, self.opts, packed, want_stats) if not want_stats else self.b.render_packed(U, self.opts, packed)
         if self.collective:
             if hasattr(self.b, "before_gather"):
                 self.b.before_gather()
-            dist.all_gather_into_tensor(self.gathered, self.packed)
-            self.b.deinterleave(self.gathered, self.image, self.w, self.h, self.world, self.rpr)
+            dist.all_gather_into_tensor(self.gathered_ring[slot], packed)
+            ev = self.b.after_gather() if hasattr(self.b, "after_gather") else None
+            self._drain()                                  # the previous frame, behind this frame's render
+            self.pending = (slot, ev)
+            if want_stats:
+                self._drain()
         return st
 
     def finish(self):
+        self._drain()
         if hasattr(self.b, "finish"):
             self.b.finish()

@@ -23,7 +23,7 @@ class OracleBackend:
     def alloc(self, rows, width):
         return torch.zeros((rows, width), dtype=torch.int32)
 
-    def render_packed(self, U, opts, packed):
+    def render_packed(self, U, opts, packed, want_stats=True):
         from raytracer_amd import dist as rdist
         h = int(U[37])
         ys = rdist.stripe_rows_of(h, opts.stripe_rank, opts.stripe_world) if opts.stripe_rows else np.arange(h)
@@ -89,6 +89,18 @@ def _worker(rank, world, port, q):
         frame.step(U)
         ref, _ = oracle.render(mine["nodes"], mine["tri_pos"], mine["tri_nor"], U, mode=1, want=("rgba8",))
         ok = np.array_equal(frame.image.numpy(), ref["rgba8"].view(np.int32)[:, :, 0]) and (ref["rgba8"][..., 0] > 0).any()
+        # asynchronous, software-pipelined loop: frame i is de-interleaved by step i+1 (or finish()), two buffer pairs alternate
+        cams = [(0.0, 0.0, 3.0), (0.3, 0.1, 2.5), (-0.2, 0.2, 2.0), (0.1, -0.3, 3.5)]
+        refs = []
+        for k, cam in enumerate(cams):
+            Uk = rt.make_uniforms(w, h, cam_pos=cam)
+            Uk[20:36] = np.eye(4, dtype=np.float32).reshape(-1)
+            refs.append(oracle.render(mine["nodes"], mine["tri_pos"], mine["tri_nor"], Uk, mode=1, want=("rgba8",))[0]["rgba8"].view(np.int32)[:, :, 0])
+            frame.step(Uk, want_stats=False)
+            if k >= 1:
+                ok = ok and np.array_equal(frame.image.numpy(), refs[k - 1])
+        frame.finish()
+        ok = ok and np.array_equal(frame.image.numpy(), refs[-1]) and not np.array_equal(refs[-1], refs[-2])
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
