@@ -159,7 +159,9 @@ enum { RT_MODE_PRIMARY = 0,   /* primary ray, N.L shading, no shadow rays (BASEL
        RT_MODE_PT      = 2 }; /* full computeLighting_optimized (cfg 4) */
 enum { RT_LAYOUT_WIDE64 = 0,  /* default: 64-byte two-child records + precomputed triangle edges */
        RT_LAYOUT_AOS32  = 1 };/* traverse the 32-byte interchange records directly (A/B baseline) */
-enum { RT_FLAG_COUNT_WORK = 1 }; /* also count box/triangle tests (slower; for parity + roofline bytes) */
+enum { RT_FLAG_COUNT_WORK = 1,   /* also count box/triangle tests (slower; for parity + roofline bytes) */
+       RT_FLAG_TEXTURED   = 2 }; /* albedo of every hit from the bound surface (materials + map_Kd textures) instead of
+                                    the constant of compute.wgsl:372; see "material / texture shading" below */
 
 typedef struct rt_render_opts {
   int32_t mode;           /* RT_MODE_* */
@@ -204,6 +206,40 @@ uint32_t rt_packed_rows(uint32_t height, int32_t stripe_rows, int32_t stripe_ran
  * rows_per_rank x width x elem_bytes) into a full image; all pointers are device memory. */
 int rt_deinterleave_device(rt_ctx* ctx, const void* d_packed, void* d_image, uint32_t width, uint32_t height,
                            uint32_t elem_bytes, int32_t stripe_rows, int32_t stripe_world, uint32_t rows_per_rank);
+
+/* ------------------------------------------------------------------ material / texture shading (extension) */
+/* The reference shades every surface with one constant albedo (compute.wgsl:372; no WGSL reads a vt, texture or
+ * material) although its scenes carry MTL files and textures (models/ *.mtl, map_Kd).  north_star asks for "the
+ * simple material/texture shading"; with RT_FLAG_TEXTURED the albedo at a hit is defined as
+ *   material id < 0 or >= n_materials            -> the reference constant (1, 0.84, 0)
+ *   albedo = Kd, times the map_Kd texel when the material names a texture
+ *   uv     = fma(uv2, v, fma(uv1, u, uv0 * ((1 - u) - v)))     (u, v: Moeller-Trumbore barycentrics; the form of the
+ *                                                               normal interpolation, compute.wgsl:291)
+ *   f = uv - floor(uv) (repeat);  x = min(u32(f.x * W), W-1);  y = min(u32((1 - f.y) * H), H-1)   (OBJ v = 0 = bottom row)
+ *   nearest texel, channel = f32(byte) / 255, no filtering, no colour-space conversion
+ * and it replaces `albedo` at the primary hit (compute.wgsl:372,378,408) and, per bounce, the factor of
+ * `throughput *= albedo` (:400) by the albedo of the surface the bounce ray hit.  Everything else is unchanged. */
+typedef struct rt_material_rec {
+  float   kd[3];       /* tinyobj material_t::diffuse (Kd) */
+  int32_t texture;     /* texture slot of map_Kd, -1 = none */
+} rt_material_rec;
+#define RT_MAX_TEXTURES 64
+
+/* Per-corner texcoords and per-face material ids of the mesh given to rt_set_mesh (the vt / usemtl data loadObj drops,
+ * script.js:176-196; tinyobj attrib_t::texcoords, index_t::texcoord_index, mesh_t::material_ids).  The next
+ * rt_build_lbvh (or this call, if the LBVH is already built) reorders them into BVH order next to triPos / triNor:
+ * one 32-byte record per triangle {u0 v0 u1 v1 u2 v2 bits(material id) 0}.  material_ids may be NULL (all -1). */
+int rt_set_surface(rt_ctx* ctx, const float* texcoords, uint32_t n_tex, const uint32_t* tex_idx /* [3T] */,
+                   const int32_t* material_ids /* [T] or NULL */);
+int rt_get_tri_uv(rt_ctx* ctx, float* tri_uv /* [8T], BVH order */);
+/* For imported BVHs (rt_set_bvh / rt_load_bvh / rt_bvh_adopt_device): the records directly, in that BVH's order. */
+int rt_set_tri_uv(rt_ctx* ctx, const float* tri_uv, uint32_t n_tri);
+int rt_set_materials(rt_ctx* ctx, const rt_material_rec* materials, uint32_t n_materials);
+/* Raw 8-bit RGB, row 0 = top of the image, rows tightly packed.  Decoding image files is the host's business. */
+int rt_set_texture(rt_ctx* ctx, uint32_t slot, const uint8_t* rgb8, uint32_t width, uint32_t height);
+/* Multi-GPU: the BVH-order records as device memory (for the host's RCCL broadcast), and their adoption (copied). */
+int rt_tri_uv_device(rt_ctx* ctx, void** d_tri_uv, uint64_t* bytes);
+int rt_adopt_tri_uv_device(rt_ctx* ctx, const void* d_tri_uv, uint32_t n_tri);
 
 /* ------------------------------------------------------------------ multi-GPU: BVH replication (host drives RCCL) */
 /* The flat buffers of a built/imported BVH as device memory, for ncclBroadcast by the host. */

@@ -30,6 +30,50 @@ class RenderStats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class _Surface(C.Structure):
+    _fields_ = [("tri_uv", C.c_void_p), ("materials", C.c_void_p), ("n_materials", C.c_uint32), ("texels", C.c_void_p),
+                ("tex_table", C.c_void_p), ("n_textures", C.c_uint32)]
+
+
+class Surface:
+    """Material/texture extension inputs in the oracle's layout (rt_oracle.h:orc_surface).
+    tri_uv [T,8] BVH order; materials: list of (kd_rgb, texture_slot or -1); textures: list of uint8 [H,W,3] arrays."""
+
+    def __init__(self, tri_uv, materials, textures):
+        self.tri_uv = np.ascontiguousarray(tri_uv, np.float32).reshape(-1, 8)
+        m = np.zeros((max(len(materials), 1), 4), np.float32)
+        for i, (kd, slot) in enumerate(materials):
+            m[i, :3] = kd
+            m[i, 3:4].view(np.uint32)[0] = 0xFFFFFFFF if slot is None or slot < 0 else slot
+        self.materials, self.n_materials = m, len(materials)
+        table, tex = [], []
+        off = 0
+        for t in textures:
+            t = np.ascontiguousarray(t, np.uint8)
+            h, w = t.shape[:2]
+            px = t[..., 0].astype(np.uint32) | (t[..., 1].astype(np.uint32) << 8) | (t[..., 2].astype(np.uint32) << 16) | np.uint32(0xFF000000)
+            tex.append(px.reshape(-1))
+            table.append((off, w, h, 0))
+            off += w * h
+        self.texels = np.concatenate(tex) if tex else np.zeros(1, np.uint32)
+        self.table = np.asarray(table if table else [(0, 0, 0, 0)], np.uint32)
+        self.n_textures = len(textures)
+        self.c = _Surface(self.tri_uv.ctypes.data, self.materials.ctypes.data, self.n_materials, self.texels.ctypes.data,
+                          self.table.ctypes.data, self.n_textures)
+
+
+def gather_tri_uv(texcoords, tex_idx, material_ids, order):
+    tc = np.ascontiguousarray(texcoords, np.float32).reshape(-1)
+    ti = np.ascontiguousarray(tex_idx, np.uint32).reshape(-1)
+    o = np.ascontiguousarray(order, np.uint32)
+    mid = None if material_ids is None else np.ascontiguousarray(material_ids, np.int32)
+    out = np.zeros((o.size, 8), np.float32)
+    lib().orc_gather_tri_uv(tc.ctypes.data_as(C.c_void_p), ti.ctypes.data_as(C.c_void_p),
+                            None if mid is None else mid.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.c_void_p), o.size,
+                            out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 def build(force=False):
     """Compile liboracle.so with the committed recipe (oracle/Makefile)."""
     if force or not os.path.exists(_LIB_PATH):
@@ -65,6 +109,9 @@ def lib():
         L.orc_build_sah.restype = C.c_int
         L.orc_build_sah.argtypes = [f32p, f32p, u32p, u32p, C.c_uint32, C.c_int, f32p, C.c_uint32, C.POINTER(C.c_uint32),
                                     f32p, f32p, u32p, C.POINTER(C.c_double)]
+        L.orc_set_surface.restype = None; L.orc_set_surface.argtypes = [C.c_void_p]
+        L.orc_gather_tri_uv.restype = None
+        L.orc_gather_tri_uv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_make_uniforms.restype = None
         L.orc_make_uniforms.argtypes = [C.POINTER(C.c_double), C.c_double, C.c_double, C.POINTER(C.c_double),
                                         C.c_uint32, C.c_uint32, C.c_float, f32p]
@@ -172,8 +219,9 @@ def make_uniforms(cam_pos=(0.0, 0.0, 5.0), yaw=0.0, pitch=0.0, sliders=DEFAULT_S
 
 
 def render(nodes, tri_pos, tri_nor, uniforms, mode=MODE_PRIMARY, gi_samples=32, gi_bounces=3, soft_samples=4,
-           max_stack=12, rows=None, n_threads=1, want=("rgba8", "hit_tri", "hit_t"), encoding=1):
-    """rows = (begin, end, step) or None for all. Returns (outputs dict, stats dict)."""
+           max_stack=12, rows=None, n_threads=1, want=("rgba8", "hit_tri", "hit_t"), encoding=1, surface=None):
+    """rows = (begin, end, step) or None for all. Returns (outputs dict, stats dict).
+    surface: a Surface (material/texture extension) or None for the reference's constant albedo."""
     nodes = np.ascontiguousarray(nodes, np.float32).reshape(-1)
     tp = np.ascontiguousarray(tri_pos, np.float32).reshape(-1)
     tn = np.ascontiguousarray(tri_nor, np.float32).reshape(-1)
@@ -187,8 +235,14 @@ def render(nodes, tri_pos, tri_nor, uniforms, mode=MODE_PRIMARY, gi_samples=32, 
     if "hit_t" in want: out["hit_t"] = np.zeros((h, w), np.float32)
     ptr = lambda k: out[k].ctypes.data_as(C.c_void_p) if k in out else None
     st = RenderStats()
-    rc = lib().orc_render(nodes, nodes.size // 8, tp, tn, tp.size // 12, U, C.byref(opts),
-                          ptr("rgba8"), ptr("hit_tri"), ptr("hit_t"), C.byref(st))
+    if surface is not None and surface.tri_uv.shape[0] != tp.size // 12:
+        raise ValueError("surface.tri_uv must have one record per triangle")
+    lib().orc_set_surface(C.addressof(surface.c) if surface is not None else None)
+    try:
+        rc = lib().orc_render(nodes, nodes.size // 8, tp, tn, tp.size // 12, U, C.byref(opts),
+                              ptr("rgba8"), ptr("hit_tri"), ptr("hit_t"), C.byref(st))
+    finally:
+        lib().orc_set_surface(None)
     if rc != 0:
         raise RuntimeError(f"orc_render failed: {rc}")
     return out, st.as_dict()

@@ -414,6 +414,7 @@ struct Scene {
   const float* tri_pos; const float* tri_nor; uint32_t n_tri;
   int max_stack, gi_samples, gi_bounces, soft_samples, mode;
   int enc;   // node record encoding: 1 = v1 (reference), 2 = v2
+  const orc_surface* surf;   // material/texture extension (NULL = the reference's constant albedo)
 };
 uint32_t* g_visit_counts = nullptr;        // analysis only, single-threaded use: internal steps per node
 struct Counters {
@@ -462,14 +463,14 @@ inline bool tri_intersect(V3 ro, V3 rd, V3 v0, V3 v1, V3 v2, float& t, float& u,
   return (det > 1e-10f) & (u >= 0.0f) & (v >= 0.0f) & ((u + v) <= 1.0f) & (t > 1e-10f);
 }
 
-struct Hit { float t; V3 n; uint32_t tri; };
+struct Hit { float t; V3 n; uint32_t tri; float u, v; };
 
 // web/compute.wgsl:259-346 — literal transcription incl. the 12-entry stack and far-child drop (F9)
 Hit traverse(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Counters& C) {
   int stack[64];
   const int MAX_STACK = S.max_stack;
   int sp = 0, cur = 0;
-  float bestT = maxDist; V3 bestN = v3(0, 0, 0); uint32_t bestTri = 0xFFFFFFFFu;
+  float bestT = maxDist; V3 bestN = v3(0, 0, 0); uint32_t bestTri = 0xFFFFFFFFu; float bestU = 0.0f, bestV = 0.0f;
   C.box += 1;  // the root is the only box not first tested as somebody's child
   for (;;) {
     if (cur < 0 || sp >= MAX_STACK) break;
@@ -485,7 +486,7 @@ Hit traverse(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Counters& C) {
           float t, u, v;
           bool hit = tri_intersect(ro, rd, va, vb, vc, t, u, v);
           if (hit && t < bestT) {                                          // :286 strict <
-            bestT = t; bestTri = ti; C.hitupd += 1;
+            bestT = t; bestTri = ti; bestU = u; bestV = v; C.hitupd += 1;
             V3 n0 = tri_n(S, ti * 3 + 0), n1 = tri_n(S, ti * 3 + 1), n2 = tri_n(S, ti * 3 + 2);
             bestN = normalize(fma3(n2, v, fma3(n1, u, n0 * ((1.0f - u) - v))));  // :291
           }
@@ -517,7 +518,7 @@ Hit traverse(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Counters& C) {
       if (sp > 0) { sp -= 1; cur = stack[sp]; } else break;
     }
   }
-  return Hit{bestT, bestN, bestTri};
+  return Hit{bestT, bestN, bestTri, bestU, bestV};
 }
 
 // web/compute.wgsl:166-194 — walks only the child0 chain (F8)
@@ -610,6 +611,36 @@ inline V3 mat_mul3(const float* m, V3 v) {
             (m[2] * v.x + m[6] * v.y) + m[10] * v.z);
 }
 
+// Material / texture extension (north_star "simple material/texture shading"; the reference has none: compute.wgsl:372
+// is a constant).  Definition, shared word for word with rt_trace.hip:hit_albedo and include/rtcore.h:
+//   material id < 0 (or no surface bound)  -> the reference constant (1, 0.84, 0)
+//   albedo = Kd, times the map_Kd texel when the material has a texture
+//   uv = fma(uv2, v, fma(uv1, u, uv0 * ((1 - u) - v)))           (the form of the normal interpolation, compute.wgsl:291)
+//   repeat wrap f = uv - floor(uv); x = min(u32(f.x * W), W-1); y = min(u32((1 - f.y) * H), H-1)   (OBJ v = 0 is the bottom row)
+//   nearest texel, channel value = f32(byte) / 255
+V3 hit_albedo(const Scene& S, const Hit& h) {
+  const V3 ref = v3(1.0f, 0.84f, 0.0f);
+  const orc_surface* sf = S.surf;
+  if (!sf) return ref;
+  const float* r = sf->tri_uv + 8 * (size_t)h.tri;
+  const int32_t mat = (int32_t)f_bits(r[6]);
+  if (mat < 0 || (uint32_t)mat >= sf->n_materials) return ref;
+  const float* m = sf->materials + 4 * (size_t)mat;
+  V3 kd = v3(m[0], m[1], m[2]);
+  const uint32_t slot = f_bits(m[3]);
+  if (slot >= sf->n_textures) return kd;
+  const float w0 = (1.0f - h.u) - h.v;
+  const float tu = fmaf(r[4], h.v, fmaf(r[2], h.u, r[0] * w0));
+  const float tv = fmaf(r[5], h.v, fmaf(r[3], h.u, r[1] * w0));
+  const float fu = tu - floorf(tu), fv = tv - floorf(tv);
+  const uint32_t* tt = sf->tex_table + 4 * (size_t)slot;
+  const uint32_t W = tt[1], H = tt[2];
+  const uint32_t x = std::min(sat_u32(fu * (float)W), W - 1u), y = std::min(sat_u32((1.0f - fv) * (float)H), H - 1u);
+  const uint32_t px = sf->texels[(size_t)tt[0] + (size_t)y * W + x];
+  const V3 c = v3((float)(px & 255u) / 255.0f, (float)((px >> 8) & 255u) / 255.0f, (float)((px >> 16) & 255u) / 255.0f);
+  return kd * c;
+}
+
 struct Pixel { float r, g, b, a; uint32_t tri; float t; };
 thread_local uint32_t* g_work_img = nullptr;   // optional per-pixel box-test count (analysis only)
 
@@ -625,7 +656,7 @@ Pixel compute_lighting(const Scene& S, const float* U, V3 ro_w, V3 rd_w, uint32_
   if (hit0.t >= 1e19f) return Pixel{0, 0, 0, 1, 0xFFFFFFFFu, hit0.t};
   V3 hit_pos = fma3(rd_os, hit0.t, ro_os);
   V3 n_os = hit0.n;
-  V3 albedo = v3(1.0f, 0.84f, 0.0f);
+  V3 albedo = hit_albedo(S, hit0);                      // compute.wgsl:372 when no surface is bound
   V3 indirect = v3(0, 0, 0);
   if (S.mode == ORC_MODE_PT) {
     const uint32_t GI = (uint32_t)S.gi_samples, NB = (uint32_t)S.gi_bounces;
@@ -646,7 +677,7 @@ Pixel compute_lighting(const Scene& S, const float* U, V3 ro_w, V3 rd_w, uint32_
         V3 nB = hb.n;
         float dS = direct_radiance(S, pB, nB, light_os, pixelIndex, time, C);
         indirect = indirect + throughput * dS;
-        throughput = throughput * albedo;
+        throughput = throughput * (S.surf ? hit_albedo(S, hb) : albedo);   // :400 — the constant is every surface's albedo there
         ro_b = fma3(nB, 0.0001f, pB);
         n_b = nB;
       }
@@ -689,6 +720,25 @@ void render_pixel(const Scene& S, const float* U, uint32_t gx, uint32_t gy, uint
 }  // namespace
 
 static uint32_t* g_work_request = nullptr;
+static const orc_surface* g_surface = nullptr;
+extern "C" void orc_set_surface(const orc_surface* s) { g_surface = s; }
+
+// BVH-order surface records from the loadObj-style arrays: record i describes input triangle order[i]
+extern "C" void orc_gather_tri_uv(const float* texcoords, const uint32_t* tex_idx, const int32_t* material_ids,
+                                  const uint32_t* order, uint32_t n_tri, float* tri_uv) {
+  for (uint32_t i = 0; i < n_tri; ++i) {
+    const uint32_t t = order[i];
+    float* r = tri_uv + 8 * (size_t)i;
+    for (int k = 0; k < 3; ++k) {
+      const size_t ti = tex_idx[3 * (size_t)t + k];
+      r[2 * k + 0] = texcoords[2 * ti + 0];
+      r[2 * k + 1] = texcoords[2 * ti + 1];
+    }
+    r[6] = bits_f((uint32_t)(material_ids ? material_ids[t] : -1));
+    r[7] = 0.0f;
+  }
+}
+
 extern "C" void orc_set_work_image(uint32_t* img) { g_work_request = img; }
 extern "C" void orc_set_visit_counts(uint32_t* per_node) { g_visit_counts = per_node; }   // closest-hit internal steps per node (run with n_threads = 1)   // box tests per pixel of the next orc_render calls
 
@@ -699,7 +749,7 @@ extern "C" int orc_render(const float* nodes, uint32_t n_nodes, const float* tri
   if (o->max_stack < 1 || o->max_stack > 64 || o->row_step < 1) return -2;
   if (n_nodes == 0 || n_tri == 0) return -3;
   Scene S{nodes, n_nodes, tri_pos, tri_nor, n_tri, o->max_stack, o->gi_samples, o->gi_bounces, o->soft_samples, o->mode,
-          o->node_encoding == 2 ? 2 : 1};
+          o->node_encoding == 2 ? 2 : 1, g_surface};
   const uint32_t w = sat_u32(U[36]), h = sat_u32(U[37]);
   const float time_h = (float)orc_hash_u32(sat_u32(U[38]));      // compute.wgsl:444
   int r0 = std::max(0, o->row_begin), r1 = std::min<int>((int)h, o->row_end), rs = o->row_step;

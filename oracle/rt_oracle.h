@@ -118,6 +118,21 @@ int orc_render(const float* nodes, uint32_t n_nodes, const float* tri_pos, const
                uint32_t n_tri, const float uniforms[44], const orc_render_opts* opts,
                uint8_t* rgba8, uint32_t* hit_tri, float* hit_t, orc_render_stats* stats);
 
+/* Material / texture extension (no reference counterpart: compute.wgsl:372 is a constant albedo; the
+ * sampling rule is written out at rt_oracle.cpp:hit_albedo and include/rtcore.h).  While a surface is set, orc_render
+ * takes the albedo of every hit from it; NULL restores the reference's constant. */
+typedef struct orc_surface {
+  const float*    tri_uv;       /* [8T], BVH order: u0 v0 u1 v1 u2 v2 bits(material id, i32) 0 */
+  const float*    materials;    /* [4M]: Kd.r Kd.g Kd.b bits(texture slot, 0xFFFFFFFF = none) */
+  uint32_t        n_materials;
+  const uint32_t* texels;       /* all textures back to back, one u32 per texel: R | G<<8 | B<<16 | 255<<24, row 0 = top */
+  const uint32_t* tex_table;    /* [4 per texture]: first texel, width, height, 0 */
+  uint32_t        n_textures;
+} orc_surface;
+void orc_set_surface(const orc_surface* s);
+void orc_gather_tri_uv(const float* texcoords, const uint32_t* tex_idx, const int32_t* material_ids /* or NULL */,
+                       const uint32_t* order, uint32_t n_tri, float* tri_uv);
+
 /* analysis aid: when non-NULL, later orc_render calls also write box tests per pixel (w*h) */
 void orc_set_work_image(uint32_t* img);
 /* analysis aid (single-threaded renders only): counts closest-hit internal steps per node */

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _abi
-from ._abi import (FLAG_COUNT_WORK, LAYOUT_AOS32, LAYOUT_WIDE64, MODE_PRIMARY, MODE_PT, MODE_SHADOW,  # noqa: F401
+from ._abi import (FLAG_COUNT_WORK, FLAG_TEXTURED, LAYOUT_AOS32, LAYOUT_WIDE64, MODE_PRIMARY, MODE_PT, MODE_SHADOW,  # noqa: F401
                    NODES_V1, NODES_V2)
 
 _L = _abi.load()          # raises ImportError when the HIP extension is not built
@@ -211,6 +211,46 @@ class Context:
 
     def load_bvh(self, path):
         self._chk(_L.rt_load_bvh(self._h, str(path).encode()))
+
+    # ---- material / texture shading (extension, rtcore.h)
+    def set_surface(self, mesh):
+        """Texcoords + per-face material ids of the mesh last given to set_mesh (before or after build_lbvh)."""
+        if mesh.texcoords is None or mesh.tex_idx is None:
+            raise ValueError("mesh has no texcoords")
+        self._chk(_L.rt_set_surface(self._h, _vp(mesh.texcoords), mesh.texcoords.shape[0], _vp(mesh.tex_idx), _vp(mesh.material_ids)))
+
+    def tri_uv(self):
+        out = np.zeros((self.counts()[0], 8), np.float32)
+        self._chk(_L.rt_get_tri_uv(self._h, _vp(out)))
+        return out
+
+    def set_tri_uv(self, tri_uv):
+        a = np.ascontiguousarray(tri_uv, np.float32).reshape(-1, 8)
+        self._chk(_L.rt_set_tri_uv(self._h, _vp(a), a.shape[0]))
+
+    def set_materials(self, materials):
+        """materials: sequence of (kd_rgb, texture_slot or -1/None)."""
+        arr = (_abi.MaterialRec * max(len(materials), 1))()
+        for i, (kd, slot) in enumerate(materials):
+            arr[i].kd[:] = [float(x) for x in kd]
+            arr[i].texture = -1 if slot is None else int(slot)
+        self._chk(_L.rt_set_materials(self._h, arr, len(materials)))
+
+    def set_texture(self, slot, rgb8):
+        """rgb8: uint8 [H, W, 3], row 0 = top of the image."""
+        a = np.ascontiguousarray(rgb8, np.uint8)
+        if a.ndim != 3 or a.shape[2] != 3:
+            raise ValueError("texture must be uint8 [H, W, 3]")
+        self._chk(_L.rt_set_texture(self._h, slot, _vp(a), a.shape[1], a.shape[0]))
+
+    def tri_uv_device(self):
+        """-> (device address or 0, bytes) of the BVH-order surface records."""
+        p, n = C.c_void_p(), C.c_uint64()
+        self._chk(_L.rt_tri_uv_device(self._h, C.byref(p), C.byref(n)))
+        return (p.value or 0), n.value
+
+    def adopt_tri_uv_device(self, d_tri_uv, n_tri):
+        self._chk(_L.rt_adopt_tri_uv_device(self._h, C.c_void_p(d_tri_uv), n_tri))
 
     # ---- hot path 2
     def render(self, uniforms, opts=None, want=("rgba8", "hit_tri", "hit_t")):

@@ -13,6 +13,8 @@ RT_OK, RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_IO, RT_ERR_LIMIT, RT
 MODE_PRIMARY, MODE_SHADOW, MODE_PT = 0, 1, 2
 LAYOUT_WIDE64, LAYOUT_AOS32 = 0, 1
 FLAG_COUNT_WORK = 1
+FLAG_TEXTURED = 2
+MAX_TEXTURES = 64
 NODES_V1, NODES_V2 = 1, 2
 
 # every symbol include/rtcore.h declares (tests/test_abi.py checks the header against this list)
@@ -25,6 +27,8 @@ SYMBOLS = [
     "rt_render_opts_default", "rt_render", "rt_render_device", "rt_packed_rows", "rt_deinterleave_device",
     "rt_bvh_view_get", "rt_bvh_export_device", "rt_bvh_adopt_device", "rt_synchronize", "rt_stream",
     "rt_profile_begin", "rt_profile_end", "rt_set_node_encoding", "rt_get_node_encoding",
+    "rt_set_surface", "rt_get_tri_uv", "rt_set_tri_uv", "rt_set_materials", "rt_set_texture", "rt_tri_uv_device",
+    "rt_adopt_tri_uv_device",
 ]
 
 
@@ -67,6 +71,10 @@ class RenderStats(C.Structure):
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class MaterialRec(C.Structure):
+    _fields_ = [("kd", C.c_float * 3), ("texture", C.c_int32)]
 
 
 class BvhView(C.Structure):
@@ -140,6 +148,13 @@ def load():
         "rt_get_node_encoding": (C.c_int, [vp]),
         "rt_profile_begin": (C.c_int, [vp]),
         "rt_profile_end": (C.c_int, [vp, vp, vp, vp]),
+        "rt_set_surface": (C.c_int, [vp, vp, u32, vp, vp]),
+        "rt_get_tri_uv": (C.c_int, [vp, vp]),
+        "rt_set_tri_uv": (C.c_int, [vp, vp, u32]),
+        "rt_set_materials": (C.c_int, [vp, C.POINTER(MaterialRec), u32]),
+        "rt_set_texture": (C.c_int, [vp, u32, vp, u32, u32]),
+        "rt_tri_uv_device": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_uint64)]),
+        "rt_adopt_tri_uv_device": (C.c_int, [vp, vp, u32]),
     }
     for name in SYMBOLS:
         fn = getattr(L, name)          # AttributeError here = the library does not export a declared symbol

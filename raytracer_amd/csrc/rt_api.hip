@@ -63,6 +63,20 @@ struct rt_ctx {
   bool have_bvh = false;
   int node_encoding = RT_NODES_V1;   // encoding of the next built / imported / adopted node buffer
 
+  // surface extension (rtcore.h "material / texture shading")
+  DevBuf<float> texcoords, tri_uv;
+  DevBuf<uint32_t> tidx;
+  DevBuf<int32_t> matid;
+  bool surface_set = false, surface_has_mat = false;   // mesh-order arrays uploaded for the current mesh
+  uint32_t tri_uv_n = 0;                                // triangles described by tri_uv (0 = none)
+  DevBuf<float4> materials;
+  uint32_t n_materials = 0;
+  std::vector<rt_material_rec> materials_host;
+  DevBuf<uint32_t> texels[RT_MAX_TEXTURES];
+  RtTexDev tex_host[RT_MAX_TEXTURES] = {};
+  DevBuf<RtTexDev> tex_table;
+  uint32_t n_textures = 0;                              // highest set slot + 1
+
   // render scratch
   DevBuf<uint32_t> r_tile_counter, r_list;
   DevBuf<unsigned long long> r_stats;
@@ -170,6 +184,9 @@ extern "C" void rt_destroy(rt_ctx* ctx) {
   ctx->child.release(); ctx->parent.release();
   ctx->own_nodes.release(); ctx->own_tri_pos.release(); ctx->own_tri_nor.release();
   ctx->wide.release(); ctx->tri_pre.release();
+  ctx->texcoords.release(); ctx->tri_uv.release(); ctx->tidx.release(); ctx->matid.release(); ctx->materials.release();
+  for (auto& t : ctx->texels) t.release();
+  ctx->tex_table.release();
   ctx->r_tile_counter.release(); ctx->r_list.release(); ctx->r_stats.release(); ctx->o_rgba.release(); ctx->o_tri.release(); ctx->o_t.release();
   for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : ctx->prof_ev) if (ev) (void)hipEventDestroy(ev);
@@ -215,6 +232,7 @@ extern "C" int rt_set_mesh(rt_ctx* ctx, const float* positions, uint32_t n_vert,
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->n_vert = n_vert; ctx->n_nor = n_nor; ctx->n_tri_mesh = n_tri;
   ctx->built = false;
+  ctx->surface_set = false;      // texcoords / material ids belong to the previous mesh
   return RT_OK;
 }
 
@@ -275,6 +293,12 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
   ctx->bvh.nodes = ctx->own_nodes.p; ctx->bvh.tri_pos = ctx->own_tri_pos.p; ctx->bvh.tri_nor = ctx->own_tri_nor.p;
   ctx->bvh.n_nodes = N; ctx->bvh.n_tri = T; ctx->bvh.owns_interchange = true;
   HIPCHK(hipEventRecord(ctx->ev[6], s));
+  ctx->tri_uv_n = 0;
+  if (ctx->surface_set) {          // surface records into BVH order, next to triPos / triNor (counted in ms_pack)
+    HIPCHK(ctx->tri_uv.ensure((size_t)T * 8));
+    rt_launch_gather_uv(ctx->texcoords.p, ctx->tidx.p, ctx->surface_has_mat ? ctx->matid.p : nullptr, ctx->vals_a.p, T, ctx->tri_uv.p, s);
+    ctx->tri_uv_n = T;
+  }
   int rc = finish_bvh(ctx);
   if (rc != RT_OK) return rc;
   HIPCHK(hipEventRecord(ctx->ev[7], s));
@@ -379,7 +403,7 @@ extern "C" int rt_set_bvh(rt_ctx* ctx, const float* nodes, uint32_t n_nodes, con
   rc = validate_nodes(ctx, nodes, n_nodes, n_tri);
   if (rc != RT_OK) return rc;
   DeviceGuard g(ctx->device);
-  ctx->have_bvh = false; ctx->built = false;
+  ctx->have_bvh = false; ctx->built = false; ctx->tri_uv_n = 0;
   HIPCHK(ctx->own_nodes.ensure((size_t)n_nodes * 8));
   HIPCHK(ctx->own_tri_pos.ensure((size_t)n_tri * 12));
   HIPCHK(ctx->own_tri_nor.ensure((size_t)n_tri * 12));
@@ -460,13 +484,124 @@ extern "C" int rt_bvh_adopt_device(rt_ctx* ctx, const rt_bvh_view* v) {
     return ctx->fail(RT_ERR_INVALID, "rt_bvh_adopt_device: buffers smaller than the counts imply");
   { const int lrc = check_encoding_limits(ctx, "rt_bvh_adopt_device", v->n_nodes, v->n_tri); if (lrc != RT_OK) return lrc; }
   DeviceGuard g(ctx->device);
-  ctx->have_bvh = false; ctx->built = false;
+  ctx->have_bvh = false; ctx->built = false; ctx->tri_uv_n = 0;
   ctx->bvh = RtBvhDev();
   ctx->bvh.nodes = static_cast<float*>(v->d_nodes);
   ctx->bvh.tri_pos = static_cast<float*>(v->d_tri_pos);
   ctx->bvh.tri_nor = static_cast<float*>(v->d_tri_nor);
   ctx->bvh.n_nodes = v->n_nodes; ctx->bvh.n_tri = v->n_tri; ctx->bvh.owns_interchange = false;
   return finish_bvh(ctx);   // the pack kernel range-checks every child / leaf index on the device
+}
+
+// ================================================================ material / texture shading (extension)
+extern "C" int rt_set_surface(rt_ctx* ctx, const float* texcoords, uint32_t n_tex, const uint32_t* tex_idx, const int32_t* material_ids) {
+  if (!ctx) return RT_ERR_INVALID;
+  const uint32_t T = ctx->n_tri_mesh;
+  if (T == 0) return ctx->fail(RT_ERR_INVALID, "rt_set_surface: call rt_set_mesh first");
+  if (!texcoords || !tex_idx || n_tex == 0) return ctx->fail(RT_ERR_INVALID, "rt_set_surface: NULL / empty texcoords");
+  for (size_t i = 0; i < (size_t)T * 3; ++i)   // a wild index would fault the GPU: check on the host
+    if (tex_idx[i] >= n_tex) return ctx->fail(RT_ERR_INVALID, "rt_set_surface: texcoord index out of range");
+  DeviceGuard g(ctx->device);
+  hipStream_t s = ctx->stream;
+  HIPCHK(ctx->texcoords.ensure((size_t)n_tex * 2));
+  HIPCHK(ctx->tidx.ensure((size_t)T * 3));
+  HIPCHK(hipMemcpyAsync(ctx->texcoords.p, texcoords, sizeof(float) * 2 * n_tex, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(ctx->tidx.p, tex_idx, sizeof(uint32_t) * 3 * (size_t)T, hipMemcpyHostToDevice, s));
+  if (material_ids) {
+    HIPCHK(ctx->matid.ensure(T));
+    HIPCHK(hipMemcpyAsync(ctx->matid.p, material_ids, sizeof(int32_t) * (size_t)T, hipMemcpyHostToDevice, s));
+  }
+  ctx->surface_has_mat = material_ids != nullptr;
+  ctx->surface_set = true;
+  if (ctx->built && ctx->have_bvh && ctx->bvh.n_tri == T) {   // the LBVH of this mesh already exists: reorder now
+    HIPCHK(ctx->tri_uv.ensure((size_t)T * 8));
+    rt_launch_gather_uv(ctx->texcoords.p, ctx->tidx.p, ctx->surface_has_mat ? ctx->matid.p : nullptr, ctx->vals_a.p, T, ctx->tri_uv.p, s);
+    HIPCHK(hipGetLastError());
+    ctx->tri_uv_n = T;
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  return RT_OK;
+}
+
+extern "C" int rt_get_tri_uv(rt_ctx* ctx, float* tri_uv) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (!tri_uv) return ctx->fail(RT_ERR_INVALID, "rt_get_tri_uv: NULL output");
+  if (!ctx->have_bvh || ctx->tri_uv_n == 0 || ctx->tri_uv_n != ctx->bvh.n_tri)
+    return ctx->fail(RT_ERR_INVALID, "rt_get_tri_uv: no surface records for the current BVH (rt_set_surface + rt_build_lbvh, or rt_set_tri_uv)");
+  DeviceGuard g(ctx->device);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipMemcpy(tri_uv, ctx->tri_uv.p, sizeof(float) * 8 * (size_t)ctx->tri_uv_n, hipMemcpyDeviceToHost));
+  return RT_OK;
+}
+
+extern "C" int rt_set_tri_uv(rt_ctx* ctx, const float* tri_uv, uint32_t n_tri) {
+  NEED_BVH();
+  if (!tri_uv || n_tri != ctx->bvh.n_tri) return ctx->fail(RT_ERR_INVALID, "rt_set_tri_uv: need one record per triangle of the current BVH");
+  DeviceGuard g(ctx->device);
+  HIPCHK(ctx->tri_uv.ensure((size_t)n_tri * 8));
+  HIPCHK(hipMemcpyAsync(ctx->tri_uv.p, tri_uv, sizeof(float) * 8 * (size_t)n_tri, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->tri_uv_n = n_tri;
+  return RT_OK;
+}
+
+extern "C" int rt_tri_uv_device(rt_ctx* ctx, void** d_tri_uv, uint64_t* bytes) {
+  NEED_BVH();
+  if (!d_tri_uv || !bytes) return ctx->fail(RT_ERR_INVALID, "rt_tri_uv_device: NULL output");
+  const bool have = ctx->tri_uv_n != 0 && ctx->tri_uv_n == ctx->bvh.n_tri;
+  *d_tri_uv = have ? ctx->tri_uv.p : nullptr;
+  *bytes = have ? 32ull * ctx->tri_uv_n : 0;
+  return RT_OK;
+}
+
+extern "C" int rt_adopt_tri_uv_device(rt_ctx* ctx, const void* d_tri_uv, uint32_t n_tri) {
+  NEED_BVH();
+  if (!d_tri_uv || n_tri != ctx->bvh.n_tri) return ctx->fail(RT_ERR_INVALID, "rt_adopt_tri_uv_device: need one record per triangle of the current BVH");
+  DeviceGuard g(ctx->device);
+  HIPCHK(ctx->tri_uv.ensure((size_t)n_tri * 8));
+  HIPCHK(hipMemcpyAsync(ctx->tri_uv.p, d_tri_uv, 32ull * n_tri, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->tri_uv_n = n_tri;
+  return RT_OK;
+}
+
+extern "C" int rt_set_materials(rt_ctx* ctx, const rt_material_rec* materials, uint32_t n_materials) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (n_materials > 0 && !materials) return ctx->fail(RT_ERR_INVALID, "rt_set_materials: NULL materials");
+  if (n_materials > (1u << 20)) return ctx->fail(RT_ERR_LIMIT, "rt_set_materials: more than 2^20 materials");
+  for (uint32_t i = 0; i < n_materials; ++i)
+    if (materials[i].texture >= RT_MAX_TEXTURES) return ctx->fail(RT_ERR_LIMIT, "rt_set_materials: texture slot >= RT_MAX_TEXTURES");
+  DeviceGuard g(ctx->device);
+  std::vector<float> rec(4 * (size_t)std::max<uint32_t>(n_materials, 1), 0.0f);
+  for (uint32_t i = 0; i < n_materials; ++i) {
+    rec[4 * i + 0] = materials[i].kd[0]; rec[4 * i + 1] = materials[i].kd[1]; rec[4 * i + 2] = materials[i].kd[2];
+    const uint32_t slot = materials[i].texture < 0 ? 0xFFFFFFFFu : (uint32_t)materials[i].texture;
+    std::memcpy(&rec[4 * i + 3], &slot, 4);
+  }
+  HIPCHK(ctx->materials.ensure(std::max<uint32_t>(n_materials, 1)));
+  HIPCHK(hipMemcpyAsync(ctx->materials.p, rec.data(), sizeof(float) * rec.size(), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->materials_host.assign(materials, materials + n_materials);
+  ctx->n_materials = n_materials;
+  return RT_OK;
+}
+
+extern "C" int rt_set_texture(rt_ctx* ctx, uint32_t slot, const uint8_t* rgb8, uint32_t width, uint32_t height) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (slot >= RT_MAX_TEXTURES) return ctx->fail(RT_ERR_LIMIT, "rt_set_texture: slot >= RT_MAX_TEXTURES");
+  if (!rgb8 || width == 0 || height == 0 || width > 32768 || height > 32768) return ctx->fail(RT_ERR_INVALID, "rt_set_texture: bad image");
+  DeviceGuard g(ctx->device);
+  const size_t n = (size_t)width * height;
+  std::vector<uint32_t> px(n);
+  for (size_t i = 0; i < n; ++i) px[i] = (uint32_t)rgb8[3 * i] | ((uint32_t)rgb8[3 * i + 1] << 8) | ((uint32_t)rgb8[3 * i + 2] << 16) | 0xFF000000u;
+  HIPCHK(hipStreamSynchronize(ctx->stream));          // a frame in flight may still read the old texels
+  HIPCHK(ctx->texels[slot].ensure(n));
+  HIPCHK(hipMemcpy(ctx->texels[slot].p, px.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+  ctx->tex_host[slot].texels = ctx->texels[slot].p; ctx->tex_host[slot].w = width; ctx->tex_host[slot].h = height;
+  ctx->n_textures = std::max(ctx->n_textures, slot + 1);
+  HIPCHK(ctx->tex_table.ensure(RT_MAX_TEXTURES));
+  HIPCHK(hipMemcpy(ctx->tex_table.p, ctx->tex_host, sizeof(ctx->tex_host), hipMemcpyHostToDevice));
+  return RT_OK;
 }
 
 // ================================================================ hot path 2
@@ -520,6 +655,18 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
   p.wide = ctx->bvh.wide; p.tri_pre = ctx->bvh.tri_pre; p.root_ref = ctx->bvh.root_ref; p.leaf_shift = ctx->bvh.leaf_shift;
   p.nodes_v2 = ctx->bvh.v2 ? 1 : 0;
   p.step_budget = ctx->bvh.n_nodes + 64u;
+  if (opts->flags & RT_FLAG_TEXTURED) {
+    if (ctx->tri_uv_n == 0 || ctx->tri_uv_n != ctx->bvh.n_tri)
+      return ctx->fail(RT_ERR_INVALID, "RT_FLAG_TEXTURED: no surface records for the current BVH (rt_set_surface before rt_build_lbvh, or rt_set_tri_uv)");
+    for (uint32_t i = 0; i < ctx->n_materials; ++i) {
+      const int32_t t = ctx->materials_host[i].texture;
+      if (t >= 0 && ((uint32_t)t >= ctx->n_textures || ctx->tex_host[t].texels == nullptr))
+        return ctx->fail(RT_ERR_INVALID, "RT_FLAG_TEXTURED: material " + std::to_string(i) + " names texture slot " + std::to_string(t) + ", which was never set");
+    }
+    HIPCHK(ctx->materials.ensure(1)); HIPCHK(ctx->tex_table.ensure(RT_MAX_TEXTURES));
+    p.tri_uv = reinterpret_cast<const float4*>(ctx->tri_uv.p); p.materials = ctx->materials.p; p.textures = ctx->tex_table.p;
+    p.n_materials = ctx->n_materials; p.n_textures = ctx->n_textures;
+  }
   std::memcpy(p.U, uniforms, sizeof(float) * 44);
   p.mode = opts->mode; p.gi_samples = opts->gi_samples; p.gi_bounces = opts->gi_bounces; p.soft_samples = opts->soft_samples;
   p.max_stack = opts->max_stack;

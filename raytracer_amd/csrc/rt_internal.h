@@ -36,7 +36,14 @@ struct RtBvhDev {
   float    root_box[8] = {};   // host copy of node 0 (mn.xyz, A | mx.xyz, B) for the screen-space cull rectangle
 };
 
+// Surface extension (include/rtcore.h "material / texture shading")
+struct RtTexDev { const uint32_t* texels; uint32_t w, h; };   // texel = R | G<<8 | B<<16 | 255<<24, row 0 = top
+
 struct RtRenderParams {
+  const float4*   tri_uv;          // [2T] {u0 v0 u1 v1} {u2 v2 bits(material) 0}, BVH order; NULL unless RT_FLAG_TEXTURED
+  const float4*   materials;       // [n_materials] {Kd.rgb, bits(texture slot)}
+  const RtTexDev* textures;        // [n_textures]
+  uint32_t n_materials, n_textures;
   const float*  nodes;
   const float*  tri_pos;
   const float*  tri_nor;
@@ -102,8 +109,12 @@ uint32_t rt_shard_words();
 uint32_t rt_shard_stride();
 // ev0/ev1 (optional) are recorded immediately before/after the traversal kernel proper
 // want_stats == false skips the k_stats_final reduction (p.stats is then not written)
+// p.tri_uv != NULL selects the textured instantiation
 void rt_launch_render(const RtRenderParams& p, int layout, bool count_work, bool want_stats, int n_cu, hipStream_t s,
                       hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+// BVH-order surface records: record i <- input triangle order[i]
+void rt_launch_gather_uv(const float* texcoords, const uint32_t* tex_idx, const int32_t* material_ids, const uint32_t* order,
+                         uint32_t n_tri, float* tri_uv, hipStream_t s);
 // Conservative screen-space bound of the root box (host, double precision): fills p.cull_*.
 void rt_cull_rect(RtRenderParams& p, const float root_box[8]);
 void rt_launch_deinterleave(const void* packed, void* image, uint32_t width, uint32_t height, uint32_t elem_bytes,

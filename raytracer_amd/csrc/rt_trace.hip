@@ -41,6 +41,10 @@ struct Scene {
   uint32_t step_budget;    // > number of nodes: a valid tree never exhausts it; a cyclic (corrupt) import cannot hang the GPU
   uint32_t* stk_ref;       // this thread's LDS column, stride TBLK
   float*    stk_t;
+  const float4* tri_uv;    // surface extension (rtcore.h "material / texture shading")
+  const float4* materials;
+  const RtTexDev* textures;
+  uint32_t n_materials, n_textures;
 };
 
 // web/compute.wgsl:91-104
@@ -273,6 +277,27 @@ RT_DEV V3 hit_normal(const Scene& S, const Hit& h) {
   return normalize3(fma3(n2, h.v, fma3(n1, h.u, n0 * ((1.0f - h.u) - h.v))));
 }
 
+// Albedo of the surface at a hit: the definition in include/rtcore.h ("material / texture shading"), the same
+// statements as the CPU checker restates them.
+RT_DEV V3 hit_albedo(const Scene& S, const Hit& h) {
+  const V3 ref = v3(1.0f, 0.84f, 0.0f);                                  // compute.wgsl:372
+  const float4 a = S.tri_uv[2 * (size_t)h.tri + 0], b = S.tri_uv[2 * (size_t)h.tri + 1];
+  const int mat = (int)__float_as_uint(b.z);
+  if (mat < 0 || (uint32_t)mat >= S.n_materials) return ref;
+  const float4 m = S.materials[mat];
+  const V3 kd = xyz(m);
+  const uint32_t slot = __float_as_uint(m.w);
+  if (slot >= S.n_textures) return kd;
+  const float w0 = (1.0f - h.u) - h.v;
+  const float tu = __fmaf_rn(b.x, h.v, __fmaf_rn(a.z, h.u, a.x * w0));
+  const float tv = __fmaf_rn(b.y, h.v, __fmaf_rn(a.w, h.u, a.y * w0));
+  const float fu = tu - floorf(tu), fv = tv - floorf(tv);
+  const RtTexDev t = S.textures[slot];
+  const uint32_t x = min(sat_u32(fu * (float)t.w), t.w - 1u), y = min(sat_u32((1.0f - fv) * (float)t.h), t.h - 1u);
+  const uint32_t px = t.texels[(size_t)y * t.w + x];
+  return kd * v3((float)(px & 255u) / 255.0f, (float)((px >> 8) & 255u) / 255.0f, (float)((px >> 16) & 255u) / 255.0f);
+}
+
 // ---------------------------------------------------------------- shading
 struct Shade { int mode, gi_samples, gi_bounces, soft_samples; };
 struct RayCount { uint32_t primary, shadow, bounce; };
@@ -362,7 +387,7 @@ RT_DEV PrimaryRay primary_ray(const float* U, uint32_t gx, uint32_t gy, uint32_t
 }
 
 // web/compute.wgsl:349-410
-template <int LAYOUT, bool COUNT>
+template <int LAYOUT, bool COUNT, bool TEX>
 RT_DEV PixelOut shade_pixel(const Scene& S, const Shade& sh, const float* U, uint32_t gx, uint32_t gy, uint32_t w, uint32_t h,
                             float time_h, Work& W, RayCount& R) {
   const PrimaryRay pr = primary_ray(U, gx, gy, w, h);
@@ -377,7 +402,7 @@ RT_DEV PixelOut shade_pixel(const Scene& S, const Shade& sh, const float* U, uin
 
   const V3 hit_pos = fma3(rd_os, hit0.t, ro_os);
   const V3 n_os = hit_normal(S, hit0);
-  const V3 albedo = v3(1.0f, 0.84f, 0.0f);
+  const V3 albedo = TEX ? hit_albedo(S, hit0) : v3(1.0f, 0.84f, 0.0f);
   V3 indirect = v3(0.0f, 0.0f, 0.0f);
   if (sh.mode == RT_MODE_PT) {
     const uint32_t GI = (uint32_t)sh.gi_samples, NB = (uint32_t)sh.gi_bounces;
@@ -398,7 +423,7 @@ RT_DEV PixelOut shade_pixel(const Scene& S, const Shade& sh, const float* U, uin
         const V3 nB = hit_normal(S, hb);
         const float dS = direct_radiance<LAYOUT, COUNT>(S, sh, pB, nB, light_os, pixelIndex, time_h, W, R);
         indirect = indirect + throughput * dS;
-        throughput = throughput * albedo;
+        throughput = throughput * (TEX ? hit_albedo(S, hb) : albedo);      // :400
         ro_b = fma3(nB, 0.0001f, pB);
         n_b = nB;
       }
@@ -565,7 +590,7 @@ __global__ __launch_bounds__(TBLK) void k_compact(const RtRenderParams p) {
 // ranges, each with its own queue head on its own cache line.  A wave drains its home shard
 // (blocks with equal blockIdx % 8 share an XCD and get neighbouring shards = one image region,
 // for L2 locality only), then steals from whichever shard a cheap load scan shows non-empty.
-template <int LAYOUT, bool COUNT>
+template <int LAYOUT, bool COUNT, bool TEX>
 __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   uint32_t* stk_ref = reinterpret_cast<uint32_t*>(smem);
@@ -578,6 +603,7 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
   S.wide = p.wide; S.tri_pre = p.tri_pre;
   S.root_ref = p.root_ref; S.leaf_shift = p.leaf_shift; S.v2 = p.nodes_v2 != 0; S.max_stack = p.max_stack; S.step_budget = p.step_budget;
   S.stk_ref = stk_ref + threadIdx.x; S.stk_t = stk_t + threadIdx.x;
+  S.tri_uv = p.tri_uv; S.materials = p.materials; S.textures = p.textures; S.n_materials = p.n_materials; S.n_textures = p.n_textures;
   Shade sh; sh.mode = p.mode; sh.gi_samples = p.gi_samples; sh.gi_bounces = p.gi_bounces; sh.soft_samples = p.soft_samples;
 
   const int lane = threadIdx.x & 63;
@@ -610,7 +636,7 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
         const uint32_t idx = p.list[li];
         const uint32_t x = idx % p.width, lrow = idx / p.width;
         const uint32_t y = local_to_global_row(p, lrow);
-        const PixelOut o = shade_pixel<LAYOUT, COUNT>(S, sh, p.U, x, y, p.width, p.height, time_h, W, R);
+        const PixelOut o = shade_pixel<LAYOUT, COUNT, TEX>(S, sh, p.U, x, y, p.width, p.height, time_h, W, R);
         if (p.rgba8) reinterpret_cast<uint32_t*>(p.rgba8)[idx] = o.rgba;
         if (p.hit_tri) p.hit_tri[idx] = o.tri;
         if (p.hit_t) p.hit_t[idx] = o.t;
@@ -619,6 +645,20 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
     }
   }
   flush_stats<COUNT>(p, lane, R, W, pixels);
+}
+
+// surface records into BVH order (the vt / material counterpart of flattenForSSBO's triPos / triNor loop, script.js:530-545)
+__global__ __launch_bounds__(TBLK) void k_gather_uv(const float* __restrict__ texcoords, const uint32_t* __restrict__ tex_idx,
+                                                    const int32_t* __restrict__ material_ids, const uint32_t* __restrict__ order,
+                                                    uint32_t n_tri, float4* __restrict__ tri_uv) {
+  const uint32_t i = blockIdx.x * TBLK + threadIdx.x;
+  if (i >= n_tri) return;
+  const uint32_t t = order[i];
+  const float2* tc = reinterpret_cast<const float2*>(texcoords);
+  const float2 a = tc[tex_idx[3 * (size_t)t + 0]], b = tc[tex_idx[3 * (size_t)t + 1]], c = tc[tex_idx[3 * (size_t)t + 2]];
+  const int32_t m = material_ids ? material_ids[t] : -1;
+  tri_uv[2 * (size_t)i + 0] = make_float4(a.x, a.y, b.x, b.y);
+  tri_uv[2 * (size_t)i + 1] = make_float4(c.x, c.y, __uint_as_float((uint32_t)m), 0.0f);
 }
 
 template <typename T>
@@ -640,15 +680,18 @@ __global__ __launch_bounds__(TBLK) void k_deinterleave(const T* __restrict__ pac
 // late behind another one (measured: with a 4-blocks/CU grid and 3 resident, a quarter of the
 // waves started 400 us into a 650 us launch).
 uint32_t rt_render_grid(int n_cu) { return (uint32_t)n_cu * 4u; }   // upper bound (sizes the per-block stats slots)
-static uint32_t resident_grid(int n_cu, int max_stack) {
-  static int per_cu[33] = {0};
-  if (per_cu[max_stack] == 0) {
+static uint32_t resident_grid(int n_cu, int max_stack, bool tex) {
+  static int per_cu[2][33] = {};
+  int& slot = per_cu[tex ? 1 : 0][max_stack];
+  if (slot == 0) {
     int nb = 0;
     const size_t lds = (size_t)max_stack * TBLK * 8;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_render<RT_LAYOUT_WIDE64, true>), TBLK, lds) != hipSuccess || nb < 1) nb = 2;
-    per_cu[max_stack] = nb > 4 ? 4 : nb;
+    const hipError_t e = tex ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_render<RT_LAYOUT_WIDE64, true, true>), TBLK, lds)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_render<RT_LAYOUT_WIDE64, true, false>), TBLK, lds);
+    if (e != hipSuccess || nb < 1) nb = 2;
+    slot = nb > 4 ? 4 : nb;
   }
-  return (uint32_t)n_cu * (uint32_t)per_cu[max_stack];
+  return (uint32_t)n_cu * (uint32_t)slot;
 }
 uint32_t rt_cull_blocks(uint32_t n_tiles) { return (n_tiles + CULL_TPB - 1) / CULL_TPB; }
 uint32_t rt_shard_words() { return N_SHARD * (uint32_t)shard_stride_words(); }
@@ -708,18 +751,27 @@ void rt_launch_render(const RtRenderParams& p, int layout, bool count_work, bool
   const dim3 b(TBLK), gc(rt_cull_blocks(p.n_tiles));
   hipLaunchKernelGGL(k_cull, gc, b, 0, s, p);
   hipLaunchKernelGGL(k_compact, gc, b, 0, s, p);
-  const dim3 g(resident_grid(n_cu, p.max_stack));
+  const dim3 g(resident_grid(n_cu, p.max_stack, p.tri_uv != nullptr));
   const size_t lds = (size_t)p.max_stack * TBLK * (sizeof(uint32_t) + sizeof(float));
   if (ev0) (void)hipEventRecord(ev0, s);
+  const bool tex = p.tri_uv != nullptr;
+#define RT_LAUNCH_RENDER(L, C, X) hipLaunchKernelGGL((k_render<L, C, X>), g, b, lds, s, p)
   if (layout == RT_LAYOUT_WIDE64) {
-    if (count_work) hipLaunchKernelGGL((k_render<RT_LAYOUT_WIDE64, true>), g, b, lds, s, p);
-    else hipLaunchKernelGGL((k_render<RT_LAYOUT_WIDE64, false>), g, b, lds, s, p);
+    if (count_work) { if (tex) RT_LAUNCH_RENDER(RT_LAYOUT_WIDE64, true, true); else RT_LAUNCH_RENDER(RT_LAYOUT_WIDE64, true, false); }
+    else { if (tex) RT_LAUNCH_RENDER(RT_LAYOUT_WIDE64, false, true); else RT_LAUNCH_RENDER(RT_LAYOUT_WIDE64, false, false); }
   } else {
-    if (count_work) hipLaunchKernelGGL((k_render<RT_LAYOUT_AOS32, true>), g, b, lds, s, p);
-    else hipLaunchKernelGGL((k_render<RT_LAYOUT_AOS32, false>), g, b, lds, s, p);
+    if (count_work) { if (tex) RT_LAUNCH_RENDER(RT_LAYOUT_AOS32, true, true); else RT_LAUNCH_RENDER(RT_LAYOUT_AOS32, true, false); }
+    else { if (tex) RT_LAUNCH_RENDER(RT_LAYOUT_AOS32, false, true); else RT_LAUNCH_RENDER(RT_LAYOUT_AOS32, false, false); }
   }
+#undef RT_LAUNCH_RENDER
   if (ev1) (void)hipEventRecord(ev1, s);
   if (want_stats) hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(256), 0, s, p, g.x, p.local_rows * p.width, count_work ? 1 : 0);
+}
+
+void rt_launch_gather_uv(const float* texcoords, const uint32_t* tex_idx, const int32_t* material_ids, const uint32_t* order,
+                         uint32_t n_tri, float* tri_uv, hipStream_t s) {
+  hipLaunchKernelGGL(k_gather_uv, dim3((n_tri + TBLK - 1) / TBLK), dim3(TBLK), 0, s, texcoords, tex_idx, material_ids, order, n_tri,
+                     reinterpret_cast<float4*>(tri_uv));
 }
 
 void rt_launch_deinterleave(const void* packed, void* image, uint32_t width, uint32_t height, uint32_t elem_bytes,

@@ -6,6 +6,11 @@
   lattice(K)  K copies of a mesh on a ceil(cbrt K)^3 lattice, spacing 1.1, each rotated about Y
               by 2π·frac(k·0.618034), flattened (BASELINE cfg 5)
 
+Every stand-in also carries what an OBJ/MTL pair would (tinyobj attrib_t::texcoords, mesh_t::material_ids):
+spherical texcoords u = theta/2pi + 1/2, v = 1 - phi/pi per vertex, three materials in latitude bands
+(STANDIN_MATERIALS) and closed-form textures (procedural_texture) in place of the reference's JPG/PNG files under
+models/, which no GPU run can read.
+
 Host-side numpy only (scene *input*, not the hot path); seed-free and deterministic.
 """
 import numpy as np
@@ -56,7 +61,36 @@ def icosphere(levels, fine_ripple=False):
         np.add.at(vn, f[:, k], fn)
     vn /= np.maximum(np.linalg.norm(vn, axis=1, keepdims=True), 1e-30)
     idx = f.astype(np.uint32).reshape(-1)
-    return Mesh(p.astype(np.float32), vn.astype(np.float32), idx, idx.copy())
+    uv = np.stack([theta / (2.0 * np.pi) + 0.5, 1.0 - phi / np.pi], axis=1)
+    # materials in latitude bands of the face centroid: 0 textured, 1 plain Kd, 2 tinted + second texture
+    band = np.floor(np.arccos(np.clip(v[f].mean(axis=1)[:, 1], -1.0, 1.0)) / np.pi * 9.0).astype(np.int64)
+    mat = (np.clip(band, 0, 8) % 3).astype(np.int32)
+    return Mesh(p.astype(np.float32), vn.astype(np.float32), idx, idx.copy(), texcoords=uv.astype(np.float32), tex_idx=idx.copy(),
+                material_ids=mat, materials=STANDIN_MATERIALS)
+
+
+# (Kd, texture slot): what models/*.mtl would give through tinyobj material_t::diffuse / diffuse_texname
+STANDIN_MATERIALS = [((1.0, 1.0, 1.0), 0), ((0.9, 0.5, 0.2), -1), ((0.6, 0.9, 1.0), 1)]
+
+
+def procedural_texture(size=2048, variant=0):
+    """Closed-form RGB8 image [size, size, 3] (row 0 = top): colour ramps with a 32-texel checker in the third
+    channel; variant 1 swaps the channels and uses 8-texel cells."""
+    y, x = np.mgrid[0:size, 0:size]
+    cell = 32 if variant == 0 else 8
+    ramp_x = (x * 255 // max(size - 1, 1)).astype(np.uint8)
+    ramp_y = (y * 255 // max(size - 1, 1)).astype(np.uint8)
+    check = np.where(((x // cell) + (y // cell)) % 2 == 0, 255, 64).astype(np.uint8)
+    ch = [ramp_x, ramp_y, check] if variant == 0 else [check, ramp_x, ramp_y]
+    return np.ascontiguousarray(np.stack(ch, axis=2))
+
+
+def bind_standin_surface(ctx, mesh, tex_size=2048):
+    """Upload a stand-in mesh's texcoords / material ids, its materials and the two closed-form textures."""
+    ctx.set_surface(mesh)
+    ctx.set_materials(mesh.materials)
+    ctx.set_texture(0, procedural_texture(tex_size, 0))
+    ctx.set_texture(1, procedural_texture(max(tex_size // 2, 1), 1))
 
 
 def s70k():
@@ -71,6 +105,7 @@ def lattice(mesh, copies):
     side = int(np.ceil(copies ** (1.0 / 3.0) - 1e-9))
     P, N, VI, NI = [], [], [], []
     nv, nn = mesh.positions.shape[0], mesh.normals.shape[0]
+    textured = mesh.texcoords is not None and mesh.tex_idx is not None
     for k in range(copies):
         ang = 2.0 * np.pi * ((k * 0.618034) % 1.0)
         c, s = np.cos(ang), np.sin(ang)
@@ -80,4 +115,9 @@ def lattice(mesh, copies):
         N.append((mesh.normals.astype(np.float64) @ R.T).astype(np.float32))
         VI.append(mesh.vert_idx + np.uint32(k * nv))
         NI.append(mesh.norm_idx + np.uint32(k * nn))
-    return Mesh(np.concatenate(P), np.concatenate(N), np.concatenate(VI), np.concatenate(NI))
+    if not textured:
+        return Mesh(np.concatenate(P), np.concatenate(N), np.concatenate(VI), np.concatenate(NI))
+    # texcoords are shared by all copies (indices are not offset); material ids repeat per copy
+    return Mesh(np.concatenate(P), np.concatenate(N), np.concatenate(VI), np.concatenate(NI), texcoords=mesh.texcoords,
+                tex_idx=np.tile(mesh.tex_idx, copies),
+                material_ids=None if mesh.material_ids is None else np.tile(mesh.material_ids, copies), materials=mesh.materials)
