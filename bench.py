@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--layout", default="wide64", choices=["wide64", "aos32"])
     ap.add_argument("--encoding", default="auto", choices=["auto", "v1", "v2"],
                     help="node records: v1 = reference (f32-valued indices, < 2^24 nodes), v2 = u32 bit-casts")
+    ap.add_argument("--no-texture", action="store_true",
+                    help="shade with the reference's constant albedo (compute.wgsl:372) instead of the materials + textures of cfg 3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the oracle sample")
     args = ap.parse_args()
@@ -87,6 +89,8 @@ def main():
     layout = dict(wide64=rt.LAYOUT_WIDE64, aos32=rt.LAYOUT_AOS32)[args.layout]
     W, H = args.width, args.height
     ctx = rt.Context(local)
+    textured = not args.no_texture
+    tflag = rt.FLAG_TEXTURED if textured else 0
 
     # ---- hot path 1: build once on rank 0 (timed separately), replicate with RCCL
     build = None
@@ -98,6 +102,8 @@ def main():
             encoding = rt.NODES_V2
         ctx.set_node_encoding(encoding)
         ctx.set_mesh(mesh)
+        if textured:
+            ctx.set_surface(mesh)       # texcoords + material ids: reordered into BVH order by every build below
         runs = [ctx.build_lbvh() for _ in range(5)]
         runs.sort(key=lambda s: s["ms_total"])
         build = runs[len(runs) // 2]
@@ -112,13 +118,19 @@ def main():
         torch.cuda.synchronize()
         bcast_ms = (time.perf_counter() - t0) * 1e3
 
+    if textured:                        # materials + closed-form textures: small host-side descriptions, set on every rank
+        from raytracer_amd import scenes
+        ctx.set_materials(scenes.STANDIN_MATERIALS)
+        ctx.set_texture(0, scenes.procedural_texture(2048, 0))
+        ctx.set_texture(1, scenes.procedural_texture(1024, 1))
+
     # camera (B) of SURVEY §8d: pos (0,0,1.3), default sliders
     U = rt.make_uniforms(W, H, cam_pos=(0.0, 0.0, 1.3))
-    base = rt.render_opts(mode=mode, gi_samples=args.spp, layout=layout)
+    base = rt.render_opts(mode=mode, gi_samples=args.spp, layout=layout, flags=tflag)
     frame = rdist.ShardedFrame(rdist.GpuBackend(ctx, device), W, H, rank, world, base)
 
     # one counted launch (untimed): rays + work counters of this rank's share of the frame
-    copts = rt.render_opts(mode=mode, gi_samples=args.spp, layout=layout, flags=rt.FLAG_COUNT_WORK,
+    copts = rt.render_opts(mode=mode, gi_samples=args.spp, layout=layout, flags=rt.FLAG_COUNT_WORK | tflag,
                            stripe_rows=frame.opts.stripe_rows, stripe_rank=rank, stripe_world=world)
     cst = ctx.render_device(U, copts, d_rgba8=frame.packed.data_ptr())
     my_rays = cst["rays_primary"] + cst["rays_shadow"] + cst["rays_bounce"]
@@ -172,18 +184,20 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{scene_txt} ({build['n_tri']} triangles), {W}x{H}, {what}, camera B (0,0,1.3), "
-                                   f"layout {args.layout}, node records {'v2' if encoding == rt.NODES_V2 else 'v1'}",
+                                   f"layout {args.layout}, node records {'v2' if encoding == rt.NODES_V2 else 'v1'}, "
+                                   + ("textured shading: 3 materials, map_Kd 2048^2 + 1024^2 closed-form RGB8, nearest texel" if textured
+                                      else "constant albedo (compute.wgsl:372)"),
                        "mode": args.mode, "rays_per_frame": int(total_rays), "stripes": "16-row round-robin" if world > 1 else "none"},
             "lbvh_build_ms": {k: round(float(v), 4) for k, v in build.items() if k.startswith("ms_")},
             "lbvh_build_roofline_frac": round(build["algorithmic_bytes"] / (build["ms_total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
             "bvh_broadcast_ms": round(bcast_ms, 3),
             "frame_kernels_ms": round(kernel_ms, 4), "frame_kernels_ms_max_rank": round(kernel_max, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(args, world),
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(args, world, textured),
                          "kernel": "k_render", "kernel_ms": round(trav_ms, 4), "algorithmic_bytes_per_launch": int(my_bytes)},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, mesh, U, mode)
+            out["cpu_baseline"] = cpu_baseline(args, mesh, U, mode, textured)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -191,7 +205,7 @@ def main():
     ctx.close()
 
 
-def pmc_traffic(args, world):
+def pmc_traffic(args, world, textured):
     """HBM bytes per k_render launch from the PMC passes (scripts/pmc_passes.sh -> scripts/pmc_summary.py,
     2 x FETCH_SIZE + WRITE_SIZE per MI355X_MICROARCH.md), committed as profiles/traffic.json.  The counters
     need rocprofv3 runs of their own, so the figure is read back from the last committed collection and is
@@ -203,21 +217,27 @@ def pmc_traffic(args, world):
         return None
     w = t.get("workload", {})
     same = (world == 1 and w.get("scene") == args.scene and w.get("width") == args.width and w.get("height") == args.height
-            and w.get("mode") == args.mode and w.get("layout") == args.layout and (args.mode != "pt" or w.get("spp") == args.spp))
+            and w.get("mode") == args.mode and w.get("layout") == args.layout and (args.mode != "pt" or w.get("spp") == args.spp)
+            and bool(w.get("textured", False)) == textured)
     return t.get("k_render_hbm_bytes_per_launch") if same else None
 
 
-def cpu_baseline(args, mesh, U, mode):
+def cpu_baseline(args, mesh, U, mode, textured):
     """The scalar oracle ("port") on the host cores, on a bounded sample of the same frame:
     every k-th row of the 4K image, k chosen so that the sample takes ~10-30 s of CPU time."""
     from oracle import binding as oracle     # checker / baseline only — never on the product path
     cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count() or 1))
     enc = 2 if 2 * mesh.n_tri - 1 > (1 << 24) or args.encoding == "v2" else 1
     b = oracle.build_lbvh(mesh.positions, mesh.normals, mesh.vert_idx, mesh.norm_idx, encoding=enc)
+    surf = None
+    if textured:
+        from raytracer_amd import scenes
+        surf = oracle.Surface(oracle.gather_tri_uv(mesh.texcoords, mesh.tex_idx, mesh.material_ids, b["order"]), scenes.STANDIN_MATERIALS,
+                              [scenes.procedural_texture(2048, 0), scenes.procedural_texture(1024, 1)])
     H = args.height
     # probe: 8 rows spread over the frame
     _, st = oracle.render(b["nodes"], b["tri_pos"], b["tri_nor"], U, mode=mode, gi_samples=args.spp, rows=(0, H, max(1, H // 8)),
-                          n_threads=cores, want=(), encoding=enc)
+                          n_threads=cores, want=(), encoding=enc, surface=surf)
     per_row = max(st["seconds"] / max(1, len(range(0, H, max(1, H // 8)))), 1e-6)
     n_rows = int(min(H, max(8, args.cpu_seconds / per_row)))
     step = max(1, H // n_rows)
@@ -227,7 +247,7 @@ def cpu_baseline(args, mesh, U, mode):
     reps = 0
     while reps < 2 or (secs * cores < args.cpu_seconds and reps < 64):
         _, st = oracle.render(b["nodes"], b["tri_pos"], b["tri_nor"], U, mode=mode, gi_samples=args.spp, rows=(0, H, step),
-                              n_threads=cores, want=(), encoding=enc)
+                              n_threads=cores, want=(), encoding=enc, surface=surf)
         rays += st["rays_primary"] + st["rays_shadow"] + st["rays_bounce"]
         secs += st["seconds"]
         reps += 1

@@ -238,7 +238,8 @@ int rt_set_materials(rt_ctx* ctx, const rt_material_rec* materials, uint32_t n_m
 /* Raw 8-bit RGB, row 0 = top of the image, rows tightly packed.  Decoding image files is the host's business. */
 int rt_set_texture(rt_ctx* ctx, uint32_t slot, const uint8_t* rgb8, uint32_t width, uint32_t height);
 /* Multi-GPU: the BVH-order records as device memory (for the host's RCCL broadcast), and their adoption (copied). */
-int rt_tri_uv_device(rt_ctx* ctx, void** d_tri_uv, uint64_t* bytes);
+int rt_tri_uv_device(rt_ctx* ctx, void** d_tri_uv, uint64_t* bytes);   /* NULL / 0 when the current BVH has none */
+int rt_tri_uv_export_device(rt_ctx* ctx, void* d_dst, uint64_t dst_bytes /* >= 32 T */);   /* synchronous D2D copy */
 int rt_adopt_tri_uv_device(rt_ctx* ctx, const void* d_tri_uv, uint32_t n_tri);
 
 /* ------------------------------------------------------------------ multi-GPU: BVH replication (host drives RCCL) */

@@ -249,6 +249,10 @@ class Context:
         self._chk(_L.rt_tri_uv_device(self._h, C.byref(p), C.byref(n)))
         return (p.value or 0), n.value
 
+    def export_tri_uv_device(self, d_dst, n_tri):
+        """Copy the surface records into caller-owned device memory (32 B x n_tri), e.g. the buffer RCCL broadcasts."""
+        self._chk(_L.rt_tri_uv_export_device(self._h, C.c_void_p(d_dst), 32 * n_tri))
+
     def adopt_tri_uv_device(self, d_tri_uv, n_tri):
         self._chk(_L.rt_adopt_tri_uv_device(self._h, C.c_void_p(d_tri_uv), n_tri))
 

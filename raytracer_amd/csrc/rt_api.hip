@@ -554,6 +554,16 @@ extern "C" int rt_tri_uv_device(rt_ctx* ctx, void** d_tri_uv, uint64_t* bytes) {
   return RT_OK;
 }
 
+extern "C" int rt_tri_uv_export_device(rt_ctx* ctx, void* d_dst, uint64_t dst_bytes) {
+  NEED_BVH();
+  if (ctx->tri_uv_n == 0 || ctx->tri_uv_n != ctx->bvh.n_tri) return ctx->fail(RT_ERR_INVALID, "rt_tri_uv_export_device: no surface records for the current BVH");
+  if (!d_dst || dst_bytes < 32ull * ctx->tri_uv_n) return ctx->fail(RT_ERR_INVALID, "rt_tri_uv_export_device: destination too small");
+  DeviceGuard g(ctx->device);
+  HIPCHK(hipMemcpyAsync(d_dst, ctx->tri_uv.p, 32ull * ctx->tri_uv_n, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return RT_OK;
+}
+
 extern "C" int rt_adopt_tri_uv_device(rt_ctx* ctx, const void* d_tri_uv, uint32_t n_tri) {
   NEED_BVH();
   if (!d_tri_uv || n_tri != ctx->bvh.n_tri) return ctx->fail(RT_ERR_INVALID, "rt_adopt_tri_uv_device: need one record per triangle of the current BVH");

@@ -70,25 +70,35 @@ class GpuBackend:
 
 
 def replicate_bvh(ctx, rank, world, device):
-    """Broadcast rank 0's flat BVH (nodes, triPos, triNor) and adopt it on every other rank.
-    Returns the tensors that back the adopted BVH (keep them alive)."""
-    meta = torch.zeros(3, dtype=torch.int64, device=device)
+    """Broadcast rank 0's flat BVH (nodes, triPos, triNor, and the BVH-order surface records when the scene has them)
+    and adopt it on every other rank.  Returns the tensors that back the adopted BVH (keep them alive).
+    Materials and textures are small host-side descriptions: every rank sets them itself."""
+    meta = torch.zeros(4, dtype=torch.int64, device=device)
     if rank == 0:
         T, N = ctx.counts()
-        meta[0], meta[1], meta[2] = T, N, ctx.node_encoding()
+        uv_ptr, uv_bytes = ctx.tri_uv_device() if hasattr(ctx, "tri_uv_device") else (0, 0)
+        meta[0], meta[1], meta[2], meta[3] = T, N, ctx.node_encoding(), 1 if uv_bytes else 0
     dist.broadcast(meta, 0)
-    T, N, enc = int(meta[0]), int(meta[1]), int(meta[2])
+    T, N, enc, has_uv = int(meta[0]), int(meta[1]), int(meta[2]), int(meta[3])
     bufs = [torch.empty(32 * N, dtype=torch.uint8, device=device), torch.empty(48 * T, dtype=torch.uint8, device=device),
             torch.empty(48 * T, dtype=torch.uint8, device=device)]
     if rank == 0:
         ctx.export_bvh_device(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), N, T)
     for b in bufs:                      # three large broadcasts (32 B x N, 48 B x T, 48 B x T)
         dist.broadcast(b, 0)
+    uv = None
+    if has_uv:                          # 32 B x T surface records
+        uv = torch.empty(32 * T, dtype=torch.uint8, device=device)
+        if rank == 0:
+            ctx.export_tri_uv_device(uv.data_ptr(), T)
+        dist.broadcast(uv, 0)
     if torch.device(device).type == "cuda":
         torch.cuda.synchronize(device)
     if rank != 0:
         ctx.set_node_encoding(enc)          # v1 / v2 node records travel as the same 32-byte slots
         ctx.adopt_bvh_device(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), N, T)
+        if uv is not None:
+            ctx.adopt_tri_uv_device(uv.data_ptr(), T)   # copied: `uv` need not be kept
     return bufs
 
 

@@ -61,6 +61,18 @@ class FakeCtx:
             a = np.ascontiguousarray(arr, np.float32)
             ctypes.memmove(ptr, a.ctypes.data, a.nbytes)
 
+    def tri_uv_device(self):
+        uv = None if self.bvh is None else self.bvh.get("tri_uv")
+        return (0, 0) if uv is None else (uv.ctypes.data, uv.nbytes)
+
+    def export_tri_uv_device(self, dst, T):
+        uv = self.bvh["tri_uv"]
+        assert uv.nbytes == 32 * T
+        ctypes.memmove(dst, uv.ctypes.data, uv.nbytes)
+
+    def adopt_tri_uv_device(self, src, T):
+        self.adopted_uv = np.frombuffer((ctypes.c_float * (8 * T)).from_address(src), np.float32).copy().reshape(T, 8)
+
     def adopt_bvh_device(self, pn, pp, pq, N, T):
         rd = lambda p, n: np.frombuffer((ctypes.c_float * n).from_address(p), np.float32).copy()
         self.adopted = dict(nodes=rd(pn, 8 * N).reshape(N, 8), tri_pos=rd(pp, 12 * T).reshape(T, 3, 4), tri_nor=rd(pq, 12 * T).reshape(T, 3, 4))
@@ -77,8 +89,12 @@ def _worker(rank, world, port, q):
         from raytracer_amd import dist as rdist
         mesh = rt.generate_test_scene()
         bvh = oracle.build_lbvh(mesh.positions, mesh.normals, mesh.vert_idx, mesh.norm_idx) if rank == 0 else None
+        uv_ref = np.arange(16, dtype=np.float32).reshape(2, 8) / 16            # the surface records travel with the BVH
+        if rank == 0:
+            bvh["tri_uv"] = uv_ref.copy()
         ctx = FakeCtx(bvh)
         keep = rdist.replicate_bvh(ctx, rank, world, "cpu")           # BVH built on rank 0 only, broadcast to the rest
+        assert rank == 0 or np.array_equal(ctx.adopted_uv, uv_ref)
         mine = bvh if rank == 0 else ctx.adopted
         assert mine is not None and len(keep) == 3
         w, h = 50, 70                                                   # not multiples of the 16-row stripes
