@@ -1,0 +1,59 @@
+"""GPU: the repo's own C++ host (src/main.cpp -> raytracer_amd/bin/rt_host) drives the C ABI end to end:
+OBJ + MTL + PPM textures -> normalise -> LBVH build -> one frame -> PPM.  Its image must equal the oracle's."""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "raytracer_amd", "bin", "rt_host")
+
+
+def _write_ppm(path, rgb):
+    with open(path, "wb") as f:
+        f.write(b"P6\n# closed-form test texture\n%d %d\n255\n" % (rgb.shape[1], rgb.shape[0]))
+        f.write(np.ascontiguousarray(rgb, np.uint8).tobytes())
+
+
+def _read_ppm(path):
+    raw = open(path, "rb").read()
+    parts = raw.split(b"\n", 3)
+    assert parts[0] == b"P6" and parts[2] == b"255"
+    w, h = (int(x) for x in parts[1].split())
+    return np.frombuffer(parts[3], np.uint8).reshape(h, w, 3)
+
+
+@pytest.mark.parametrize("textured", [False, True])
+def test_cpp_host_frame_matches_oracle(oracle, rt, plane_obj_path, tmp_path, textured):
+    from raytracer_amd import scenes
+    assert os.path.exists(HOST), "raytracer_amd/bin/rt_host is not built (make host / __graft_entry__.build())"
+    d = tmp_path
+    shutil.copy(plane_obj_path, d / "plane.obj")
+    shutil.copy(os.path.join(ROOT, "tests", "golden", "plane_standin.mtl"), d / "plane_material.mtl")
+    texs = [scenes.procedural_texture(128, 0), scenes.procedural_texture(32, 1)]
+    _write_ppm(d / "standin_checker_0.rgb", texs[0])          # the names the MTL's map_Kd lines use
+    _write_ppm(d / "standin_checker_1.rgb", texs[1])
+    w, h = 160, 96
+    cmd = [HOST, "--obj", str(d / "plane.obj"), "--width", str(w), "--height", str(h), "--mode", "shadow", "--cam", "0", "0", "0.6",
+           "--out", str(d / "frame.ppm")] + (["--textured"] if textured else [])
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "raytracer_amd", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=env)
+    assert res.returncode == 0, res.stderr
+    info = json.loads(res.stdout.strip().splitlines()[-1])
+    assert info["triangles"] == 6298 and info["nodes"] == 12595 and info["rays"] >= w * h
+    img = _read_ppm(d / "frame.ppm")
+
+    m = rt.normalize_mesh(rt.load_obj(str(d / "plane.obj")))
+    b = oracle.build_lbvh(m.positions, m.normals, m.vert_idx, m.norm_idx)
+    surf = None
+    if textured:
+        mats = [(tuple(x["diffuse"]), i) for i, x in enumerate(m.materials)]
+        surf = oracle.Surface(oracle.gather_tri_uv(m.texcoords, m.tex_idx, m.material_ids, b["order"]), mats, texs)
+    U = rt.make_uniforms(w, h, cam_pos=(0.0, 0.0, 0.6))
+    ref, _ = oracle.render(b["nodes"], b["tri_pos"], b["tri_nor"], U, mode=1, n_threads=8, surface=surf)
+    assert (ref["hit_tri"] != 0xFFFFFFFF).mean() > 0.02
+    assert np.array_equal(img, ref["rgba8"][..., :3])
