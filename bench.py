@@ -59,6 +59,11 @@ def main():
     ap.add_argument("--layout", default="wide64", choices=["wide64", "aos32"])
     ap.add_argument("--encoding", default="auto", choices=["auto", "v1", "v2"],
                     help="node records: v1 = reference (f32-valued indices, < 2^24 nodes), v2 = u32 bit-casts")
+    ap.add_argument("--frames-in-flight", default="auto", choices=["auto", "1", "2"],
+                    help="asynchronous frames in flight per GPU (rtcore.h rt_set_frames_in_flight). auto = 1 on one GPU, so that every "
+                         "k_render launch runs alone and its duration is the kernel's own (roofline), 2 with N > 1, where a rank's "
+                         "share of the frame is small and mostly tail")
+    ap.add_argument("--no-fif2", action="store_true", help="skip the extra two-frames-in-flight loop at N = 1")
     ap.add_argument("--no-texture", action="store_true",
                     help="shade with the reference's constant albedo (compute.wgsl:372) instead of the materials + textures of cfg 3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -127,7 +132,8 @@ def main():
     # camera (B) of SURVEY §8d: pos (0,0,1.3), default sliders
     U = rt.make_uniforms(W, H, cam_pos=(0.0, 0.0, 1.3))
     base = rt.render_opts(mode=mode, gi_samples=args.spp, layout=layout, flags=tflag)
-    frame = rdist.ShardedFrame(rdist.GpuBackend(ctx, device), W, H, rank, world, base)
+    fif = (1 if world == 1 else 2) if args.frames_in_flight == "auto" else int(args.frames_in_flight)
+    frame = rdist.ShardedFrame(rdist.GpuBackend(ctx, device, frames_in_flight=fif), W, H, rank, world, base)
 
     # one counted launch (untimed): rays + work counters of this rank's share of the frame
     copts = rt.render_opts(mode=mode, gi_samples=args.spp, layout=layout, flags=rt.FLAG_COUNT_WORK | tflag,
@@ -156,6 +162,24 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms, trav_ms, _n = ctx.profile_end()   # frame pipeline (cull, compact, traversal, stats) / k_render alone
+
+    # the same K frames again with two frames in flight (only where the main loop ran with one): whole-job throughput when
+    # the tail of one frame may overlap the head of the next; reported beside `value`, never as `value` at N = 1
+    fif2 = None
+    if fif == 1 and world == 1 and not args.no_fif2:
+        frame2 = rdist.ShardedFrame(rdist.GpuBackend(ctx, device, frames_in_flight=2), W, H, rank, world, base)
+        for _ in range(args.warmup):
+            frame2.step(U, want_stats=False)
+        frame2.finish()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            frame2.step(U, want_stats=False)
+        frame2.finish()
+        torch.cuda.synchronize()
+        e2 = time.perf_counter() - t1
+        fif2 = {"value": round(my_rays * args.steps / e2 / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(e2 / args.steps * 1e3, 4)}
+        ctx.set_frames_in_flight(1)
 
     tot = torch.tensor([float(my_rays), float(my_bytes), elapsed, kernel_ms], dtype=torch.float64, device=device)
     if world > 1:
@@ -187,7 +211,7 @@ def main():
                                    f"layout {args.layout}, node records {'v2' if encoding == rt.NODES_V2 else 'v1'}, "
                                    + ("textured shading: 3 materials, map_Kd 2048^2 + 1024^2 closed-form RGB8, nearest texel" if textured
                                       else "constant albedo (compute.wgsl:372)"),
-                       "mode": args.mode, "rays_per_frame": int(total_rays), "stripes": "16-row round-robin" if world > 1 else "none"},
+                       "mode": args.mode, "rays_per_frame": int(total_rays), "frames_in_flight": fif, "stripes": "16-row round-robin" if world > 1 else "none"},
             "lbvh_build_ms": {k: round(float(v), 4) for k, v in build.items() if k.startswith("ms_")},
             "lbvh_build_roofline_frac": round(build["algorithmic_bytes"] / (build["ms_total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
             "bvh_broadcast_ms": round(bcast_ms, 3),
@@ -196,6 +220,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(args, world, textured),
                          "kernel": "k_render", "kernel_ms": round(trav_ms, 4), "algorithmic_bytes_per_launch": int(my_bytes)},
         }
+        if fif2 is not None:
+            out["two_frames_in_flight"] = fif2
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, mesh, U, mode, textured)
         print(json.dumps(out), flush=True)

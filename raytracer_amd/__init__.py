@@ -297,6 +297,14 @@ class Context:
         v = _abi.BvhView(d_nodes, 32 * n_nodes, d_tri_pos, 48 * n_tri, d_tri_nor, 48 * n_tri, n_nodes, n_tri)
         self._chk(_L.rt_bvh_adopt_device(self._h, C.byref(v)))
 
+    def set_frames_in_flight(self, n):
+        """1 (default): frames run in order on stream(); 2: asynchronous frames alternate between two frame streams."""
+        self._chk(_L.rt_set_frames_in_flight(self._h, n))
+
+    def frames_join(self, keep_latest=0):
+        """stream() waits for the asynchronous frames issued so far (all but the most recent one with keep_latest=1)."""
+        self._chk(_L.rt_frames_join(self._h, keep_latest))
+
     def synchronize(self):
         self._chk(_L.rt_synchronize(self._h))
 

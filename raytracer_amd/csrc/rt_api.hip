@@ -77,9 +77,17 @@ struct rt_ctx {
   DevBuf<RtTexDev> tex_table;
   uint32_t n_textures = 0;                              // highest set slot + 1
 
-  // render scratch
-  DevBuf<uint32_t> r_tile_counter, r_list;
-  DevBuf<unsigned long long> r_stats;
+  // render scratch, one set per frame slot (slot 0 = the context stream; slots 0/1 alternate with two frames in flight)
+  DevBuf<uint32_t> r_tile_counter[2], r_list[2];
+  DevBuf<unsigned long long> r_stats[2];
+  // frames in flight (rt_set_frames_in_flight): asynchronous frames alternate between two frame streams so that the
+  // tail of frame i (few waves left, latency-bound) overlaps the head of frame i+1
+  int frames_in_flight = 1;
+  hipStream_t fstream[2] = {nullptr, nullptr};
+  hipEvent_t f_done[2] = {nullptr, nullptr};   // recorded behind each async frame on its frame stream
+  hipEvent_t f_main = nullptr;                 // main-stream marker the frame streams wait on
+  bool f_pending[2] = {false, false};          // f_done[k] recorded and not yet joined into the context stream
+  uint32_t f_count = 0;
   DevBuf<uint8_t> o_rgba;
   DevBuf<uint32_t> o_tri;
   DevBuf<float> o_t;
@@ -103,6 +111,18 @@ struct DeviceGuard {   // makes the context's device current for the duration of
   explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; (void)hipSetDevice(dev); }
   ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
+
+// Make the context stream wait for every asynchronous frame still running on a frame stream.
+int join_frames(rt_ctx* ctx) {
+  for (int k = 0; k < 2; ++k)
+    if (ctx->f_pending[k]) {
+      hipError_t e = hipStreamWaitEvent(ctx->stream, ctx->f_done[k], 0);
+      if (e != hipSuccess) return ctx->hipfail("hipStreamWaitEvent(frame)", e);
+      ctx->f_pending[k] = false;
+    }
+  return RT_OK;
+}
+#define JOIN_FRAMES() do { const int jrc_ = join_frames(ctx); if (jrc_ != RT_OK) return jrc_; } while (0)
 
 // limits of the two node-record encodings
 int check_encoding_limits(rt_ctx* ctx, const char* who, uint64_t n_nodes, uint64_t n_tri) {
@@ -187,7 +207,13 @@ extern "C" void rt_destroy(rt_ctx* ctx) {
   ctx->texcoords.release(); ctx->tri_uv.release(); ctx->tidx.release(); ctx->matid.release(); ctx->materials.release();
   for (auto& t : ctx->texels) t.release();
   ctx->tex_table.release();
-  ctx->r_tile_counter.release(); ctx->r_list.release(); ctx->r_stats.release(); ctx->o_rgba.release(); ctx->o_tri.release(); ctx->o_t.release();
+  for (int k = 0; k < 2; ++k) {
+    ctx->r_tile_counter[k].release(); ctx->r_list[k].release(); ctx->r_stats[k].release();
+    if (ctx->fstream[k]) { (void)hipStreamSynchronize(ctx->fstream[k]); (void)hipStreamDestroy(ctx->fstream[k]); }
+    if (ctx->f_done[k]) (void)hipEventDestroy(ctx->f_done[k]);
+  }
+  if (ctx->f_main) (void)hipEventDestroy(ctx->f_main);
+  ctx->o_rgba.release(); ctx->o_tri.release(); ctx->o_t.release();
   for (auto& ev : ctx->ev) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : ctx->prof_ev) if (ev) (void)hipEventDestroy(ev);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -198,6 +224,7 @@ extern "C" const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->err.
 extern "C" int rt_synchronize(rt_ctx* ctx) {
   if (!ctx) return RT_ERR_INVALID;
   DeviceGuard g(ctx->device);
+  JOIN_FRAMES();
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return RT_OK;
 }
@@ -221,6 +248,7 @@ extern "C" int rt_set_mesh(rt_ctx* ctx, const float* positions, uint32_t n_vert,
   for (size_t i = 0; i < (size_t)n_tri * 3; ++i)   // a wild index would fault the GPU: check on the host
     if (vert_idx[i] >= n_vert || nor_idx[i] >= n_nor) return ctx->fail(RT_ERR_INVALID, "rt_set_mesh: index out of range");
   DeviceGuard g(ctx->device);
+  JOIN_FRAMES();
   HIPCHK(ctx->pos.ensure((size_t)n_vert * 3));
   HIPCHK(ctx->nor.ensure((size_t)n_nor * 3));
   HIPCHK(ctx->vidx.ensure((size_t)n_tri * 3));
@@ -243,6 +271,7 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
   { const int lrc = check_encoding_limits(ctx, "rt_build_lbvh", N, T); if (lrc != RT_OK) return lrc; }
   const bool v2 = ctx->node_encoding == RT_NODES_V2;
   DeviceGuard g(ctx->device);
+  JOIN_FRAMES();
   hipStream_t s = ctx->stream;
   HIPCHK(ctx->bounds_enc.ensure(8)); HIPCHK(ctx->bounds_f.ensure(8));
   HIPCHK(ctx->codes.ensure(T)); HIPCHK(ctx->keys_a.ensure(T)); HIPCHK(ctx->keys_b.ensure(T));
@@ -326,6 +355,7 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
 extern "C" int rt_get_bounds(rt_ctx* ctx, float bmin[3], float inv_extent[3]) {
   NEED_BUILT();
   DeviceGuard g(ctx->device);
+  JOIN_FRAMES();
   float f[8];
   HIPCHK(hipMemcpy(f, ctx->bounds_f.p, sizeof(f), hipMemcpyDeviceToHost));
   for (int k = 0; k < 3; ++k) { bmin[k] = f[k]; inv_extent[k] = f[4 + k]; }
@@ -334,12 +364,14 @@ extern "C" int rt_get_bounds(rt_ctx* ctx, float bmin[3], float inv_extent[3]) {
 extern "C" int rt_get_morton(rt_ctx* ctx, uint32_t* codes) {
   NEED_BUILT();
   DeviceGuard g(ctx->device);
+  JOIN_FRAMES();
   HIPCHK(hipMemcpy(codes, ctx->codes.p, sizeof(uint32_t) * ctx->bvh.n_tri, hipMemcpyDeviceToHost));
   return RT_OK;
 }
 extern "C" int rt_get_tri_order(rt_ctx* ctx, uint32_t* order) {
   NEED_BUILT();
   DeviceGuard g(ctx->device);
+  JOIN_FRAMES();
   HIPCHK(hipMemcpy(order, ctx->vals_a.p, sizeof(uint32_t) * ctx->bvh.n_tri, hipMemcpyDeviceToHost));
   return RT_OK;
 }
@@ -352,12 +384,14 @@ extern "C" int rt_get_counts(rt_ctx* ctx, uint32_t* n_tri, uint32_t* n_nodes) {
 extern "C" int rt_get_nodes(rt_ctx* ctx, float* nodes) {
   NEED_BVH();
   DeviceGuard g(ctx->device);
+  JOIN_FRAMES();
   HIPCHK(hipMemcpy(nodes, ctx->bvh.nodes, sizeof(float) * 8 * (size_t)ctx->bvh.n_nodes, hipMemcpyDeviceToHost));
   return RT_OK;
 }
 extern "C" int rt_get_triangles(rt_ctx* ctx, float* tri_pos, float* tri_nor) {
   NEED_BVH();
   DeviceGuard g(ctx->device);
+  JOIN_FRAMES();
   if (tri_pos) HIPCHK(hipMemcpy(tri_pos, ctx->bvh.tri_pos, sizeof(float) * 12 * (size_t)ctx->bvh.n_tri, hipMemcpyDeviceToHost));
   if (tri_nor) HIPCHK(hipMemcpy(tri_nor, ctx->bvh.tri_nor, sizeof(float) * 12 * (size_t)ctx->bvh.n_tri, hipMemcpyDeviceToHost));
   return RT_OK;
@@ -403,6 +437,7 @@ extern "C" int rt_set_bvh(rt_ctx* ctx, const float* nodes, uint32_t n_nodes, con
   rc = validate_nodes(ctx, nodes, n_nodes, n_tri);
   if (rc != RT_OK) return rc;
   DeviceGuard g(ctx->device);
+  JOIN_FRAMES();
   ctx->have_bvh = false; ctx->built = false; ctx->tri_uv_n = 0;
   HIPCHK(ctx->own_nodes.ensure((size_t)n_nodes * 8));
   HIPCHK(ctx->own_tri_pos.ensure((size_t)n_tri * 12));
@@ -469,6 +504,7 @@ extern "C" int rt_bvh_export_device(rt_ctx* ctx, const rt_bvh_view* dst) {
   if (dst->nodes_bytes < nb || dst->tri_pos_bytes < tb || dst->tri_nor_bytes < tb)
     return ctx->fail(RT_ERR_INVALID, "rt_bvh_export_device: destination buffers too small");
   DeviceGuard g(ctx->device);
+  JOIN_FRAMES();
   HIPCHK(hipMemcpyAsync(dst->d_nodes, ctx->bvh.nodes, nb, hipMemcpyDeviceToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(dst->d_tri_pos, ctx->bvh.tri_pos, tb, hipMemcpyDeviceToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(dst->d_tri_nor, ctx->bvh.tri_nor, tb, hipMemcpyDeviceToDevice, ctx->stream));
@@ -484,6 +520,7 @@ extern "C" int rt_bvh_adopt_device(rt_ctx* ctx, const rt_bvh_view* v) {
     return ctx->fail(RT_ERR_INVALID, "rt_bvh_adopt_device: buffers smaller than the counts imply");
   { const int lrc = check_encoding_limits(ctx, "rt_bvh_adopt_device", v->n_nodes, v->n_tri); if (lrc != RT_OK) return lrc; }
   DeviceGuard g(ctx->device);
+  JOIN_FRAMES();
   ctx->have_bvh = false; ctx->built = false; ctx->tri_uv_n = 0;
   ctx->bvh = RtBvhDev();
   ctx->bvh.nodes = static_cast<float*>(v->d_nodes);
@@ -502,6 +539,7 @@ extern "C" int rt_set_surface(rt_ctx* ctx, const float* texcoords, uint32_t n_te
   for (size_t i = 0; i < (size_t)T * 3; ++i)   // a wild index would fault the GPU: check on the host
     if (tex_idx[i] >= n_tex) return ctx->fail(RT_ERR_INVALID, "rt_set_surface: texcoord index out of range");
   DeviceGuard g(ctx->device);
+  JOIN_FRAMES();
   hipStream_t s = ctx->stream;
   HIPCHK(ctx->texcoords.ensure((size_t)n_tex * 2));
   HIPCHK(ctx->tidx.ensure((size_t)T * 3));
@@ -529,6 +567,7 @@ extern "C" int rt_get_tri_uv(rt_ctx* ctx, float* tri_uv) {
   if (!ctx->have_bvh || ctx->tri_uv_n == 0 || ctx->tri_uv_n != ctx->bvh.n_tri)
     return ctx->fail(RT_ERR_INVALID, "rt_get_tri_uv: no surface records for the current BVH (rt_set_surface + rt_build_lbvh, or rt_set_tri_uv)");
   DeviceGuard g(ctx->device);
+  JOIN_FRAMES();
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipMemcpy(tri_uv, ctx->tri_uv.p, sizeof(float) * 8 * (size_t)ctx->tri_uv_n, hipMemcpyDeviceToHost));
   return RT_OK;
@@ -538,6 +577,7 @@ extern "C" int rt_set_tri_uv(rt_ctx* ctx, const float* tri_uv, uint32_t n_tri) {
   NEED_BVH();
   if (!tri_uv || n_tri != ctx->bvh.n_tri) return ctx->fail(RT_ERR_INVALID, "rt_set_tri_uv: need one record per triangle of the current BVH");
   DeviceGuard g(ctx->device);
+  JOIN_FRAMES();
   HIPCHK(ctx->tri_uv.ensure((size_t)n_tri * 8));
   HIPCHK(hipMemcpyAsync(ctx->tri_uv.p, tri_uv, sizeof(float) * 8 * (size_t)n_tri, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -559,6 +599,7 @@ extern "C" int rt_tri_uv_export_device(rt_ctx* ctx, void* d_dst, uint64_t dst_by
   if (ctx->tri_uv_n == 0 || ctx->tri_uv_n != ctx->bvh.n_tri) return ctx->fail(RT_ERR_INVALID, "rt_tri_uv_export_device: no surface records for the current BVH");
   if (!d_dst || dst_bytes < 32ull * ctx->tri_uv_n) return ctx->fail(RT_ERR_INVALID, "rt_tri_uv_export_device: destination too small");
   DeviceGuard g(ctx->device);
+  JOIN_FRAMES();
   HIPCHK(hipMemcpyAsync(d_dst, ctx->tri_uv.p, 32ull * ctx->tri_uv_n, hipMemcpyDeviceToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return RT_OK;
@@ -568,6 +609,7 @@ extern "C" int rt_adopt_tri_uv_device(rt_ctx* ctx, const void* d_tri_uv, uint32_
   NEED_BVH();
   if (!d_tri_uv || n_tri != ctx->bvh.n_tri) return ctx->fail(RT_ERR_INVALID, "rt_adopt_tri_uv_device: need one record per triangle of the current BVH");
   DeviceGuard g(ctx->device);
+  JOIN_FRAMES();
   HIPCHK(ctx->tri_uv.ensure((size_t)n_tri * 8));
   HIPCHK(hipMemcpyAsync(ctx->tri_uv.p, d_tri_uv, 32ull * n_tri, hipMemcpyDeviceToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -582,6 +624,7 @@ extern "C" int rt_set_materials(rt_ctx* ctx, const rt_material_rec* materials, u
   for (uint32_t i = 0; i < n_materials; ++i)
     if (materials[i].texture >= RT_MAX_TEXTURES) return ctx->fail(RT_ERR_LIMIT, "rt_set_materials: texture slot >= RT_MAX_TEXTURES");
   DeviceGuard g(ctx->device);
+  JOIN_FRAMES();
   std::vector<float> rec(4 * (size_t)std::max<uint32_t>(n_materials, 1), 0.0f);
   for (uint32_t i = 0; i < n_materials; ++i) {
     rec[4 * i + 0] = materials[i].kd[0]; rec[4 * i + 1] = materials[i].kd[1]; rec[4 * i + 2] = materials[i].kd[2];
@@ -601,6 +644,7 @@ extern "C" int rt_set_texture(rt_ctx* ctx, uint32_t slot, const uint8_t* rgb8, u
   if (slot >= RT_MAX_TEXTURES) return ctx->fail(RT_ERR_LIMIT, "rt_set_texture: slot >= RT_MAX_TEXTURES");
   if (!rgb8 || width == 0 || height == 0 || width > 32768 || height > 32768) return ctx->fail(RT_ERR_INVALID, "rt_set_texture: bad image");
   DeviceGuard g(ctx->device);
+  JOIN_FRAMES();
   const size_t n = (size_t)width * height;
   std::vector<uint32_t> px(n);
   for (size_t i = 0; i < n; ++i) px[i] = (uint32_t)rgb8[3 * i] | ((uint32_t)rgb8[3 * i + 1] << 8) | ((uint32_t)rgb8[3 * i + 2] << 16) | 0xFF000000u;
@@ -689,16 +733,29 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
   p.n_tiles = p.tiles_x * ((p.local_rows + 7) / 8);
   p.rgba8 = static_cast<uint8_t*>(d_rgba8); p.hit_tri = static_cast<uint32_t*>(d_hit_tri); p.hit_t = static_cast<float*>(d_hit_t);
   const uint32_t cull_blocks = rt_cull_blocks(p.n_tiles);
-  HIPCHK(ctx->r_tile_counter.ensure(rt_shard_words() + 32 + cull_blocks));
-  HIPCHK(ctx->r_stats.ensure(8 + (size_t)rt_render_grid(ctx->n_cu) * 8 + p.n_tiles));
-  HIPCHK(ctx->r_list.ensure((size_t)p.local_rows * p.width));
-  p.shard_stride = rt_shard_stride();
-  p.shard_heads = ctx->r_tile_counter.p; p.list_count = ctx->r_tile_counter.p + rt_shard_words();
-  p.block_total = ctx->r_tile_counter.p + rt_shard_words() + 32;
-  p.list = ctx->r_list.p;
-  p.stats = ctx->r_stats.p; p.stats_partial = ctx->r_stats.p + 8;
-  p.masks = ctx->r_stats.p + 8 + (size_t)rt_render_grid(ctx->n_cu) * 8;
+  // Frame slot + stream.  Synchronous frames (stats wanted) and contexts with one frame in flight use the context
+  // stream and slot 0 after joining whatever is still running; asynchronous frames with two in flight alternate
+  // between the two frame streams, each behind everything queued on the context stream so far.
+  const bool overlap = ctx->frames_in_flight == 2 && out == nullptr;
+  int slot = 0;
   hipStream_t s = ctx->stream;
+  if (overlap) {
+    slot = (int)(ctx->f_count++ & 1u);
+    s = ctx->fstream[slot];
+    HIPCHK(hipEventRecord(ctx->f_main, ctx->stream));
+    HIPCHK(hipStreamWaitEvent(s, ctx->f_main, 0));
+  } else {
+    JOIN_FRAMES();
+  }
+  HIPCHK(ctx->r_tile_counter[slot].ensure(rt_shard_words() + 32 + cull_blocks));
+  HIPCHK(ctx->r_stats[slot].ensure(8 + (size_t)rt_render_grid(ctx->n_cu) * 8 + p.n_tiles));
+  HIPCHK(ctx->r_list[slot].ensure((size_t)p.local_rows * p.width));
+  p.shard_stride = rt_shard_stride();
+  p.shard_heads = ctx->r_tile_counter[slot].p; p.list_count = ctx->r_tile_counter[slot].p + rt_shard_words();
+  p.block_total = ctx->r_tile_counter[slot].p + rt_shard_words() + 32;
+  p.list = ctx->r_list[slot].p;
+  p.stats = ctx->r_stats[slot].p; p.stats_partial = ctx->r_stats[slot].p + 8;
+  p.masks = ctx->r_stats[slot].p + 8 + (size_t)rt_render_grid(ctx->n_cu) * 8;
   rt_cull_rect(p, ctx->bvh.root_box);
   if (out && p.n_tiles == 0) HIPCHK(hipMemsetAsync(p.stats, 0, sizeof(unsigned long long) * 8, s));
   hipEvent_t* E = nullptr;   // {frame begin, k_render begin, k_render end, frame end}
@@ -709,6 +766,10 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
     rt_launch_render(p, opts->layout, (opts->flags & RT_FLAG_COUNT_WORK) != 0, out != nullptr, ctx->n_cu, s, E ? E[1] : nullptr, E ? E[2] : nullptr);
     HIPCHK(hipGetLastError());
     if (E) HIPCHK(hipEventRecord(E[3], s));
+  }
+  if (overlap) {
+    HIPCHK(hipEventRecord(ctx->f_done[slot], s));
+    ctx->f_pending[slot] = true;
   }
   if (out) {
     unsigned long long st[8];
@@ -721,6 +782,36 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
       (void)hipEventElapsedTime(&out->ms_kernel, E[0], E[3]);
       (void)hipEventElapsedTime(&out->ms_traverse, E[1], E[2]);
     }
+  }
+  return RT_OK;
+}
+
+extern "C" int rt_set_frames_in_flight(rt_ctx* ctx, int n) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (n != 1 && n != 2) return ctx->fail(RT_ERR_INVALID, "rt_set_frames_in_flight: 1 or 2");
+  DeviceGuard g(ctx->device);
+  JOIN_FRAMES();
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (n == 2 && !ctx->fstream[0]) {
+    for (int k = 0; k < 2; ++k) {
+      HIPCHK(hipStreamCreateWithFlags(&ctx->fstream[k], hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&ctx->f_done[k], hipEventDisableTiming));
+    }
+    HIPCHK(hipEventCreateWithFlags(&ctx->f_main, hipEventDisableTiming));
+  }
+  ctx->frames_in_flight = n;
+  return RT_OK;
+}
+
+extern "C" int rt_frames_join(rt_ctx* ctx, int keep_latest) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (keep_latest < 0 || keep_latest > 1) return ctx->fail(RT_ERR_INVALID, "rt_frames_join: keep_latest is 0 or 1");
+  DeviceGuard g(ctx->device);
+  const int latest = (int)((ctx->f_count - 1u) & 1u);     // slot of the most recent asynchronous frame
+  for (int k = 0; k < 2; ++k) {
+    if (!ctx->f_pending[k] || (keep_latest == 1 && k == latest)) continue;
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->f_done[k], 0));
+    ctx->f_pending[k] = false;
   }
   return RT_OK;
 }
@@ -740,6 +831,7 @@ extern "C" int rt_profile_end(rt_ctx* ctx, float* ms_frame_avg, float* ms_traver
   if (!ctx) return RT_ERR_INVALID;
   if (!ctx->prof_on) return ctx->fail(RT_ERR_INVALID, "rt_profile_end without rt_profile_begin");
   DeviceGuard g(ctx->device);
+  JOIN_FRAMES();
   ctx->prof_on = false;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   const uint32_t n = std::min<uint32_t>(ctx->prof_n, rt_ctx::PROF_RING);   // the ring keeps the last PROF_RING frames

@@ -32,10 +32,10 @@ def stripe_rows_of(height, rank, world, stripe_rows=STRIPE_ROWS):
 class GpuBackend:
     """Renders through librtcore.so into torch-owned device buffers (no host copies)."""
 
-    def __init__(self, ctx, device):
+    def __init__(self, ctx, device, frames_in_flight=2):
         self.ctx, self.device = ctx, device
-        # the context's own HIP stream, seen from torch, so that the two can be ordered with events
-        # (stream waits) instead of host synchronisation
+        ctx.set_frames_in_flight(frames_in_flight)     # the tail of frame i overlaps the head of frame i+1 (rtcore.h)
+        # the context's own HIP stream, seen from torch: the collective and the de-interleave of a frame are queued on it
         self.ext = torch.cuda.ExternalStream(ctx.stream(), device=device)
 
     def alloc(self, rows, width):
@@ -45,23 +45,15 @@ class GpuBackend:
         """want_stats=True synchronises the context stream (stats are read back); False is fully asynchronous."""
         return self.ctx.render_device(U, opts, d_rgba8=packed.data_ptr(), want_stats=want_stats)
 
-    def before_gather(self):
-        # the collective (torch's stream) must see the finished stripes (context stream)
-        torch.cuda.current_stream(self.device).wait_stream(self.ext)
+    def gather(self, gathered, packed, keep_latest):
+        """all-gather of a finished frame's stripes on the context stream: the stream first waits for that frame
+        (all asynchronous frames issued so far, except the most recent one when keep_latest), then torch queues the
+        collective behind it (on this stream, or on its own communication stream ordered against it)."""
+        self.ctx.frames_join(1 if keep_latest else 0)
+        with torch.cuda.stream(self.ext):
+            dist.all_gather_into_tensor(gathered, packed)
 
-    def after_gather(self):
-        """Event on torch's stream right behind the collective just queued."""
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
-        return ev
-
-    def deinterleave(self, gathered, image, width, height, world, rpr, after=None):
-        # the de-interleave kernel runs on the context's stream once ITS frame's collective (torch's stream) is done;
-        # a later frame's collective may still be in flight
-        if after is not None:
-            self.ext.wait_event(after)
-        else:
-            self.ext.wait_stream(torch.cuda.current_stream(self.device))
+    def deinterleave(self, gathered, image, width, height, world, rpr):
         self.ctx.deinterleave_device(gathered.data_ptr(), image.data_ptr(), width, height, 4, STRIPE_ROWS, world, rpr)
 
     def finish(self):
@@ -105,10 +97,11 @@ def replicate_bvh(ctx, rank, world, device):
 class ShardedFrame:
     """One frame sharded as image-space stripes over `world` ranks and gathered on every rank.
 
-    Asynchronous frame loops (step(want_stats=False)) are software-pipelined two deep: the context stream runs
-    render(i), de-interleave(i-1), render(i+1), ... while frame i's all-gather runs on torch's stream, so the
-    xGMI exchange of one frame overlaps the traversal of the next.  Two packed / gathered buffer pairs alternate;
-    render(i+2) reuses pair i only after de-interleave(i), which waited for all-gather(i)."""
+    Asynchronous frame loops (step(want_stats=False)) are software-pipelined: step i queues the render of frame i
+    first and only then the all-gather + de-interleave of frame i-1, so with two frames in flight (GpuBackend) the
+    xGMI exchange and the tail of frame i-1 overlap the traversal of frame i.  Two packed / gathered buffer pairs
+    alternate; frame i+2 reuses pair i only after all-gather(i) (a frame starts behind everything queued on the
+    context stream before it)."""
 
     DEPTH = 2
 
@@ -121,43 +114,47 @@ class ShardedFrame:
         self.opts = render_opts(mode=o.mode, gi_samples=o.gi_samples, gi_bounces=o.gi_bounces, soft_samples=o.soft_samples,
                                 max_stack=o.max_stack, layout=o.layout, flags=o.flags,
                                 stripe_rows=STRIPE_ROWS if world > 1 else 0, stripe_rank=rank, stripe_world=world)
-        depth = self.DEPTH if self.collective else 1
+        depth = self.DEPTH        # also without a collective: two frames may be in flight and must not share an output
         self.packed_ring = [backend.alloc(self.rpr, width) for _ in range(depth)]
         self.gathered_ring = [backend.alloc(self.rpr * world, width) for _ in range(depth)] if self.collective else None
         self.packed = self.packed_ring[0]
         self.image = backend.alloc(height, width) if self.collective else self.packed
         self.n_steps = 0
-        self.pending = None            # (slot, event) of the frame whose all-gather is queued but not yet de-interleaved
+        self.pending = None            # slot of the frame that is rendered (or rendering) but not yet gathered
 
-    def _drain(self):
-        if self.pending is not None:
-            slot, ev = self.pending
-            self.pending = None
-            if ev is not None:
-                self.b.deinterleave(self.gathered_ring[slot], self.image, self.w, self.h, self.world, self.rpr, after=ev)
-            else:
-                self.b.deinterleave(self.gathered_ring[slot], self.image, self.w, self.h, self.world, self.rpr)
+    def _exchange(self, slot, keep_latest):
+        packed, gathered = self.packed_ring[slot], self.gathered_ring[slot]
+        if hasattr(self.b, "gather"):
+            self.b.gather(gathered, packed, keep_latest)
+        else:
+            dist.all_gather_into_tensor(gathered, packed)
+        self.b.deinterleave(gathered, self.image, self.w, self.h, self.world, self.rpr)
 
     def step(self, U, want_stats=True):
         """Render my stripes, gather all stripes, de-interleave.  Returns this rank's render stats (or None).
-        With want_stats=False nothing synchronises with the host and the de-interleave of this frame is queued by the
-        NEXT step (or finish()): call finish() before reading self.image."""
+        With want_stats=False nothing synchronises with the host and this frame's exchange is queued by the NEXT
+        step (or finish()): call finish() before reading self.image."""
         slot = self.n_steps % len(self.packed_ring)
         self.n_steps += 1
         packed = self.packed_ring[slot]
         st = self.b.render_packed(U, self.opts, packed, want_stats) if not want_stats else self.b.render_packed(U, self.opts, packed)
-        if self.collective:
-            if hasattr(self.b, "before_gather"):
-                self.b.before_gather()
-            dist.all_gather_into_tensor(self.gathered_ring[slot], packed)
-            ev = self.b.after_gather() if hasattr(self.b, "after_gather") else None
-            self._drain()                                  # the previous frame, behind this frame's render
-            self.pending = (slot, ev)
-            if want_stats:
-                self._drain()
+        if not self.collective:
+            self.image = packed                            # world == 1: the packed rows are the frame
+            return st
+        if self.pending is not None:                       # the previous frame, while this one is traversing
+            self._exchange(self.pending, keep_latest=True)
+        self.pending = slot
+        if want_stats:
+            self.finish_exchange()
         return st
 
+    def finish_exchange(self):
+        if self.pending is not None:
+            self._exchange(self.pending, keep_latest=False)
+            self.pending = None
+
     def finish(self):
-        self._drain()
+        if self.collective:
+            self.finish_exchange()
         if hasattr(self.b, "finish"):
             self.b.finish()

@@ -29,7 +29,8 @@ def nccl_world1():
     dist.destroy_process_group()
 
 
-def test_async_frames_with_forced_collective(gpu_ctx, rt, plane_mesh, nccl_world1):
+@pytest.mark.parametrize("fif", [1, 2])
+def test_async_frames_with_forced_collective(gpu_ctx, rt, plane_mesh, nccl_world1, fif):
     import torch
 
     from raytracer_amd import dist as rdist
@@ -38,7 +39,7 @@ def test_async_frames_with_forced_collective(gpu_ctx, rt, plane_mesh, nccl_world
     w, h = 320, 200
     opts = rt.render_opts(mode=rt.MODE_SHADOW)
     dev = torch.device("cuda:0")
-    frame = rdist.ShardedFrame(rdist.GpuBackend(gpu_ctx, dev), w, h, 0, 1, opts, force_collective=True)
+    frame = rdist.ShardedFrame(rdist.GpuBackend(gpu_ctx, dev, frames_in_flight=fif), w, h, 0, 1, opts, force_collective=True)
     views = [dict(PLANE_VIEW), dict(PLANE_VIEW, cam_pos=(0.1, 0.0, 1.2)), dict(PLANE_VIEW, rot_deg=(-70.0, 10.0, 0.0))]
     gpu_ctx.profile_begin()
     for k in range(9):                      # queued back to back: render k+1 must not overwrite stripes still being gathered
@@ -50,6 +51,40 @@ def test_async_frames_with_forced_collective(gpu_ctx, rt, plane_mesh, nccl_world
     ref, _ = gpu_ctx.render(rt.make_uniforms(w, h, **views[8 % 3]), opts, want=("rgba8",))
     assert np.array_equal(got, ref["rgba8"])
     assert (ref["rgba8"][..., :3].max(axis=2) > 0).mean() > 0.05
+    gpu_ctx.set_frames_in_flight(1)
+
+
+def test_two_frames_in_flight_without_collective(gpu_ctx, rt, plane_mesh):
+    """rt_set_frames_in_flight(2): asynchronous frames alternate between two frame streams and two output buffers; every
+    frame must still be the frame of its own uniforms, and synchronous calls in between see finished results."""
+    import torch
+
+    from raytracer_amd import dist as rdist
+    gpu_ctx.set_mesh(plane_mesh)
+    gpu_ctx.build_lbvh()
+    w, h = 400, 240
+    opts = rt.render_opts(mode=rt.MODE_SHADOW)
+    dev = torch.device("cuda:0")
+    views = [dict(PLANE_VIEW), dict(PLANE_VIEW, cam_pos=(0.1, 0.0, 1.2)), dict(PLANE_VIEW, rot_deg=(-70.0, 10.0, 0.0)),
+             dict(PLANE_VIEW, cam_pos=(-0.2, 0.1, 1.0))]
+    refs = [gpu_ctx.render(rt.make_uniforms(w, h, **v), opts, want=("rgba8",))[0]["rgba8"] for v in views]
+    assert not np.array_equal(refs[0], refs[1])
+    frame = rdist.ShardedFrame(rdist.GpuBackend(gpu_ctx, dev, frames_in_flight=2), w, h, 0, 1, opts)
+    for rounds in range(3):
+        imgs = []
+        for k in range(8):
+            frame.step(rt.make_uniforms(w, h, **views[k % 4]), want_stats=False)
+            imgs.append(frame.image)                      # two alternating buffers: keep the last two
+        frame.finish()
+        a = imgs[-1].cpu().numpy().view(np.uint8).reshape(h, w, 4)
+        b = imgs[-2].cpu().numpy().view(np.uint8).reshape(h, w, 4)
+        assert np.array_equal(a, refs[7 % 4]) and np.array_equal(b, refs[6 % 4])
+        # a synchronous frame (stats) right behind asynchronous ones joins them first
+        frame.step(rt.make_uniforms(w, h, **views[1]), want_stats=False)
+        out, st = gpu_ctx.render(rt.make_uniforms(w, h, **views[2]), opts, want=("rgba8",))
+        assert np.array_equal(out["rgba8"], refs[2]) and st["pixels"] == w * h
+        frame.finish()
+    gpu_ctx.set_frames_in_flight(1)
 
 
 def test_profile_end_needs_begin(gpu_ctx, rt):

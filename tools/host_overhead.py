@@ -25,21 +25,21 @@ def main():
     ctx.set_mesh(m)
     ctx.build_lbvh()
     dev = torch.device("cuda:0")
-    for (w, h) in ((64, 64), (3840, 272)):
+    for (w, h) in ((64, 64), (3840, 272), (3840, 2160)):
         U = rt.make_uniforms(w, h, cam_pos=(0.0, 0.0, 1.3))
-        for coll in (False, True):
-            f = rdist.ShardedFrame(rdist.GpuBackend(ctx, dev), w, h, 0, 1, rt.render_opts(mode=rt.MODE_SHADOW), force_collective=coll)
+        for coll, fif in ((False, 1), (False, 2), (True, 1), (True, 2)):
+            f = rdist.ShardedFrame(rdist.GpuBackend(ctx, dev, frames_in_flight=fif), w, h, 0, 1, rt.render_opts(mode=rt.MODE_SHADOW), force_collective=coll)
             for _ in range(20):
                 f.step(U, want_stats=False)
             f.finish()
-            n = 500
+            n = 300
             t0 = time.perf_counter()
             for _ in range(n):
                 f.step(U, want_stats=False)
             t_enq = time.perf_counter() - t0
             f.finish()
             t_all = time.perf_counter() - t0
-            print(f"{w}x{h} collective={coll}: enqueue {t_enq / n * 1e6:.1f} us/step, drained {t_all / n * 1e6:.1f} us/step", flush=True)
+            print(f"{w}x{h} collective={coll} frames_in_flight={fif}: enqueue {t_enq / n * 1e6:.1f} us/step, drained {t_all / n * 1e6:.1f} us/step", flush=True)
     dist.destroy_process_group()
     ctx.close()
 
