@@ -134,23 +134,33 @@ int check_encoding_limits(rt_ctx* ctx, const char* who, uint64_t n_nodes, uint64
   return RT_OK;
 }
 
-int finish_bvh(rt_ctx* ctx) {   // derive the traversal layout from the interchange buffers
+// WIDE64 leaf ref = start | (count-1) << leaf_shift in 31 bits: 23 keeps counts up to 256 for scenes below
+// 2^23 triangles; larger scenes give the start more bits (count bits = 31 - leaf_shift)
+int leaf_shift_for(uint64_t n_tri) {
+  int sh = 23;
+  while (sh < 31 && n_tri > (1ull << sh)) sh += 1;
+  return sh;
+}
+
+// Derive the traversal layout from the interchange buffers (imports), or take the one the refit already wrote (builds).
+int finish_bvh(rt_ctx* ctx, bool packed_by_refit = false) {
   RtBvhDev& b = ctx->bvh;
   b.v2 = ctx->node_encoding == RT_NODES_V2;
-  // WIDE64 leaf ref = start | (count-1) << leaf_shift in 31 bits: 23 keeps counts up to 256 for scenes below
-  // 2^23 triangles; larger scenes give the start more bits (count bits = 31 - leaf_shift)
-  b.leaf_shift = 23;
-  while (b.leaf_shift < 31 && ((uint64_t)b.n_tri > (1ull << b.leaf_shift))) b.leaf_shift += 1;
+  b.leaf_shift = leaf_shift_for(b.n_tri);
   b.n_wide = b.n_nodes;   // imported trees may number internal nodes anywhere in [0, N)
   HIPCHK(ctx->wide.ensure((size_t)b.n_wide * 4));
   HIPCHK(ctx->tri_pre.ensure((size_t)b.n_tri * 3));
   HIPCHK(ctx->words.ensure(4));
   b.wide = ctx->wide.p; b.tri_pre = ctx->tri_pre.p;
-  HIPCHK(hipMemsetAsync(ctx->words.p, 0, 4 * sizeof(uint32_t), ctx->stream));
-  rt_launch_pack_impl(b, ctx->words.p + 0, ctx->words.p + 1, ctx->stream);
-  HIPCHK(hipGetLastError());
   uint32_t w[2] = {0, 0};
-  HIPCHK(hipMemcpyAsync(w, ctx->words.p, sizeof(w), hipMemcpyDeviceToHost, ctx->stream));
+  if (packed_by_refit) {   // Karras numbering: root = node 0, internal unless the scene is a single triangle
+    w[0] = (b.n_tri == 1) ? 0x80000000u : 0u;
+  } else {
+    HIPCHK(hipMemsetAsync(ctx->words.p, 0, 4 * sizeof(uint32_t), ctx->stream));
+    rt_launch_pack_impl(b, ctx->words.p + 0, ctx->words.p + 1, ctx->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(w, ctx->words.p, sizeof(w), hipMemcpyDeviceToHost, ctx->stream));
+  }
   HIPCHK(hipMemcpyAsync(b.root_box, b.nodes, sizeof(b.root_box), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (w[1] & 2u)
@@ -273,7 +283,7 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
   DeviceGuard g(ctx->device);
   JOIN_FRAMES();
   hipStream_t s = ctx->stream;
-  HIPCHK(ctx->bounds_enc.ensure(8)); HIPCHK(ctx->bounds_f.ensure(8));
+  HIPCHK(ctx->bounds_enc.ensure(rt_bounds_words())); HIPCHK(ctx->bounds_f.ensure(8));
   HIPCHK(ctx->codes.ensure(T)); HIPCHK(ctx->keys_a.ensure(T)); HIPCHK(ctx->keys_b.ensure(T));
   HIPCHK(ctx->vals_a.ensure(T)); HIPCHK(ctx->vals_b.ensure(T));
   HIPCHK(ctx->hist.ensure(4 * 256)); HIPCHK(ctx->tile_status.ensure(rt_sort_status_words(T)));
@@ -282,6 +292,8 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
   HIPCHK(ctx->visit.ensure(T > 1 ? T - 1 : 1));
   HIPCHK(ctx->own_nodes.ensure((size_t)N * 8)); HIPCHK(ctx->own_tri_pos.ensure((size_t)T * 12));
   HIPCHK(ctx->own_tri_nor.ensure((size_t)T * 12));
+  HIPCHK(ctx->wide.ensure((size_t)N * 4)); HIPCHK(ctx->tri_pre.ensure((size_t)T * 3));
+  const int leaf_shift = leaf_shift_for(T);
 
   RtBuildBuffers b;
   b.pos = ctx->pos.p; b.nor = ctx->nor.p; b.vidx = ctx->vidx.p; b.nidx = ctx->nidx.p; b.n_tri = T;
@@ -301,7 +313,7 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
   HIPCHK(hipEventRecord(ctx->ev[3], s));
   rt_launch_karras(b, s);
   HIPCHK(hipEventRecord(ctx->ev[4], s));
-  rt_launch_refit(b, ctx->own_nodes.p, ctx->own_tri_pos.p, ctx->own_tri_nor.p, /*fenced=*/false, v2, s);
+  rt_launch_refit(b, ctx->own_nodes.p, ctx->own_tri_pos.p, ctx->own_tri_nor.p, ctx->wide.p, ctx->tri_pre.p, leaf_shift, /*fenced=*/false, v2, s);
   HIPCHK(hipEventRecord(ctx->ev[5], s));
   HIPCHK(hipGetLastError());
   uint32_t errw = 0;
@@ -311,7 +323,7 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
   if (errw & 8u) {   // the write-through hand-off was caught stale by k_refit_verify: redo with full fences
     ctx->refit_fallbacks += 1;
     HIPCHK(hipMemsetAsync(ctx->words.p + 2, 0, sizeof(uint32_t), s));
-    rt_launch_refit(b, ctx->own_nodes.p, ctx->own_tri_pos.p, ctx->own_tri_nor.p, /*fenced=*/true, v2, s);
+    rt_launch_refit(b, ctx->own_nodes.p, ctx->own_tri_pos.p, ctx->own_tri_nor.p, ctx->wide.p, ctx->tri_pre.p, leaf_shift, /*fenced=*/true, v2, s);
     HIPCHK(hipEventRecord(ctx->ev[5], s));
     HIPCHK(hipMemcpyAsync(&errw, ctx->words.p + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -328,7 +340,7 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
     rt_launch_gather_uv(ctx->texcoords.p, ctx->tidx.p, ctx->surface_has_mat ? ctx->matid.p : nullptr, ctx->vals_a.p, T, ctx->tri_uv.p, s);
     ctx->tri_uv_n = T;
   }
-  int rc = finish_bvh(ctx);
+  int rc = finish_bvh(ctx, /*packed_by_refit=*/true);
   if (rc != RT_OK) return rc;
   HIPCHK(hipEventRecord(ctx->ev[7], s));
   HIPCHK(hipEventSynchronize(ctx->ev[7]));

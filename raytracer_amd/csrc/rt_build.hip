@@ -50,13 +50,10 @@ RT_DEV uint32_t wave_max_u32(uint32_t v) {
 }
 
 // ---------------------------------------------------------------- centroid bounds
-__global__ void k_bounds_init(uint32_t* enc) {
-  if (threadIdx.x < 3) enc[threadIdx.x] = 0xFFFFFFFFu;
-  else if (threadIdx.x < 6) enc[threadIdx.x] = 0u;
-}
-
+// Two stages, no atomics: every block leaves its six ordered-uint partials in its own slot (2048 blocks x 6 same-address
+// atomicMin/Max serialised at ~26 ns each: 53 of the kernel's 62 us at 1.3 M triangles), one block folds the slots.
 __global__ __launch_bounds__(BLK) void k_bounds(const float* __restrict__ pos, const uint32_t* __restrict__ vidx,
-                                                uint32_t n_tri, uint32_t* __restrict__ enc) {
+                                                uint32_t n_tri, uint32_t* __restrict__ part /* [gridDim.x][6] */) {
   uint32_t mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u};
   for (uint32_t t = blockIdx.x * BLK + threadIdx.x; t < n_tri; t += gridDim.x * BLK) {
     V3 c = tri_centroid(pos, vidx, t);
@@ -76,19 +73,30 @@ __global__ __launch_bounds__(BLK) void k_bounds(const float* __restrict__ pos, c
     const int k = threadIdx.x;
     uint32_t v = s[k][0];
     for (int w = 1; w < BLK / 64; ++w) v = (k < 3) ? min(v, s[k][w]) : max(v, s[k][w]);
-    if (k < 3) atomicMin(&enc[k], v); else atomicMax(&enc[k], v);
+    part[(size_t)blockIdx.x * 6 + k] = v;
   }
 }
 
-// `Bounds` uniform of morton_compute.wgsl:3-6; invExtent = 1/(max-min), 0 where the extent is 0
-__global__ void k_bounds_final(const uint32_t* enc, float* bounds_f) {
-  const int k = threadIdx.x;
-  if (k < 3) {
-    float lo = ord2f(enc[k]), hi = ord2f(enc[3 + k]);
+// fold the block partials (6 waves, one per component), then the `Bounds` uniform of morton_compute.wgsl:3-6:
+// invExtent = 1/(max-min), 0 where the extent is 0
+__global__ __launch_bounds__(384) void k_bounds_final(const uint32_t* __restrict__ part, uint32_t n_blocks, float* bounds_f) {
+  __shared__ uint32_t s[6];
+  const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
+  uint32_t v = (k < 3) ? 0xFFFFFFFFu : 0u;
+  for (uint32_t b = lane; b < n_blocks; b += 64) {
+    const uint32_t x = part[(size_t)b * 6 + k];
+    v = (k < 3) ? min(v, x) : max(v, x);
+  }
+  v = (k < 3) ? wave_min_u32(v) : wave_max_u32(v);
+  if (lane == 0) s[k] = v;
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int c = threadIdx.x;
+    float lo = ord2f(s[c]), hi = ord2f(s[3 + c]);
     float ext = hi - lo;
-    bounds_f[k] = lo;
-    bounds_f[4 + k] = (ext > 0.0f) ? (1.0f / ext) : 0.0f;
-  } else if (k == 3) { bounds_f[3] = 0.0f; bounds_f[7] = 0.0f; }
+    bounds_f[c] = lo;
+    bounds_f[4 + c] = (ext > 0.0f) ? (1.0f / ext) : 0.0f;
+  } else if (threadIdx.x == 3) { bounds_f[3] = 0.0f; bounds_f[7] = 0.0f; }
 }
 
 // ---------------------------------------------------------------- Morton codes
@@ -297,7 +305,9 @@ __global__ __launch_bounds__(BLK) void k_karras(const uint32_t* __restrict__ k, 
   const int c0 = (lo == gamma) ? (n - 1) + gamma : gamma;
   const int c1 = (hi == gamma + 1) ? (n - 1) + gamma + 1 : gamma + 1;
   child[2 * (size_t)i + 0] = c0; child[2 * (size_t)i + 1] = c1;
-  parent[c0] = i; parent[c1] = i;
+  // bit 30: this node's leaf range [lo, hi] lies inside one 256-leaf block of k_refit (block-local climb)
+  const int link = i | (((lo >> 8) == (hi >> 8)) ? (1 << 30) : 0);
+  parent[c0] = link; parent[c1] = link;
 }
 
 // ---------------------------------------------------------------- leaves + bottom-up refit
@@ -314,9 +324,11 @@ __global__ __launch_bounds__(BLK) void k_karras(const uint32_t* __restrict__ k, 
 RT_DEV unsigned long long pack2f(float a, float b) {
   return (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
 }
+// through == false: the record is only read by later kernels (its parent is block-local, or it is the root): plain stores,
+// which L2 merges into full lines instead of four 8-byte write-throughs.
 template <bool FENCED>
-RT_DEV void store_node(float* nodes, int idx, V3 mn, float a, V3 mx, float b) {
-  if (FENCED) {
+RT_DEV void store_node(float* nodes, int idx, V3 mn, float a, V3 mx, float b, bool through = true) {
+  if (FENCED || !through) {
     float4* nd = reinterpret_cast<float4*>(nodes) + 2 * (size_t)idx;
     nd[0] = make_float4(mn.x, mn.y, mn.z, a);
     nd[1] = make_float4(mx.x, mx.y, mx.z, b);
@@ -345,15 +357,31 @@ RT_DEV void load_box(const float* nodes, int idx, V3& mn, V3& mx) {
   }
 }
 
+// Block-local climb.  Block b owns sorted leaves [256 b, 256 b + 255].  k_karras marks a parent link with PARENT_LOCAL
+// when the parent's whole leaf range lies inside one such block; since an internal node's index is one end of its own
+// range, both the node and its two children then belong to that block.  For those nodes the hand-off (arrival counter +
+// sibling box) goes through LDS — no global atomic, no write-through wait — and only the nodes whose range crosses a block
+// boundary (about 1 in 128) take the global path described above.  Every record is still written to HBM (interchange
+// `nodes`, traversal `wide`), the global path reads a locally finished sibling from there.
+constexpr int PARENT_LOCAL = 1 << 30;
+constexpr int PARENT_MASK = PARENT_LOCAL - 1;
+static_assert(BLK == 256, "k_karras marks block-local nodes with (lo >> 8) == (hi >> 8)");
+
 template <bool FENCED>
 __global__ __launch_bounds__(BLK) void k_refit(const float* __restrict__ pos, const float* __restrict__ nor,
                                                const uint32_t* __restrict__ vidx, const uint32_t* __restrict__ nidx,
                                                const uint32_t* __restrict__ order, uint32_t n_tri,
                                                const int32_t* __restrict__ child, const int32_t* __restrict__ parent,
                                                uint32_t* visit, float* nodes, float* __restrict__ tri_pos,
-                                               float* __restrict__ tri_nor, bool v2) {
+                                               float* __restrict__ tri_nor, float4* __restrict__ wide, float4* __restrict__ tri_pre,
+                                               int leaf_shift, bool v2) {
+  __shared__ float s_box[2 * BLK][6];      // [0, BLK): this block's leaves, [BLK, 2 BLK): internal nodes with index in the block's range
+  __shared__ uint32_t s_visit[BLK];        // arrival counters of the block-local internal nodes
+  s_visit[threadIdx.x] = 0u;
+  __syncthreads();
   const uint32_t j = blockIdx.x * BLK + threadIdx.x;
   if (j >= n_tri) return;
+  const int first_leaf = (int)n_tri - 1;   // leaf j is node (T-1)+j, one triangle, start = j
   const uint32_t ti = order[j];
   V3 p[3];
   float4* tp = reinterpret_cast<float4*>(tri_pos) + (size_t)j * 3;
@@ -365,27 +393,66 @@ __global__ __launch_bounds__(BLK) void k_refit(const float* __restrict__ pos, co
     tp[v] = make_float4(p[v].x, p[v].y, p[v].z, 0.0f);
     tn[v] = make_float4(nn.x, nn.y, nn.z, 0.0f);
   }
+  {                                                  // traversal layout of the triangle, the statements of k_pack_tris
+    const V3 e1 = p[1] - p[0], e2 = p[2] - p[0];
+    const V3 ng = cross3(e1, e2);
+    tri_pre[3 * (size_t)j + 0] = make_float4(p[0].x, p[0].y, p[0].z, ng.x);
+    tri_pre[3 * (size_t)j + 1] = make_float4(e1.x, e1.y, e1.z, ng.y);
+    tri_pre[3 * (size_t)j + 2] = make_float4(e2.x, e2.y, e2.z, ng.z);
+  }
   // true triangle bounds (web/script.js:309-316)
   V3 mn = v3(fminf(fminf(p[0].x, p[1].x), p[2].x), fminf(fminf(p[0].y, p[1].y), p[2].y), fminf(fminf(p[0].z, p[1].z), p[2].z));
   V3 mx = v3(fmaxf(fmaxf(p[0].x, p[1].x), p[2].x), fmaxf(fmaxf(p[0].y, p[1].y), p[2].y), fmaxf(fmaxf(p[0].z, p[1].z), p[2].z));
-  int cur = (int)(n_tri - 1) + (int)j;
-  store_node<FENCED>(nodes, cur, mn, enc_index(v2, j), mx, enc_leaf_b(v2, 1u));   // A = tri_start, B = -count (script.js:348,554,558)
+  int cur = first_leaf + (int)j;
+  int cur_slot = (int)threadIdx.x;                   // LDS slot of `cur`
+  int pe = parent[cur];                              // link to the parent of `cur`
+  store_node<FENCED>(nodes, cur, mn, enc_index(v2, j), mx, enc_leaf_b(v2, 1u),   // A = tri_start, B = -count (script.js:348,554,558)
+                     pe >= 0 && !(pe & PARENT_LOCAL));
   for (;;) {
-    const int par = parent[cur];
-    if (par < 0) break;
-    if (FENCED) __threadfence();                       // release this subtree's records (agent scope)
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through stores have left this CU
-    const uint32_t arrived = atomicAdd(&visit[par], 1u);
+    if (pe < 0) break;
+    const bool local = (pe & PARENT_LOCAL) != 0;
+    const int par = pe & PARENT_MASK;
+    uint32_t arrived;
+    if (local) {
+      float* sb = s_box[cur_slot];
+      sb[0] = mn.x; sb[1] = mn.y; sb[2] = mn.z; sb[3] = mx.x; sb[4] = mx.y; sb[5] = mx.z;
+      __threadfence_block();                           // the box is in LDS before the counter moves (one LDS, in-order)
+      arrived = atomicAdd(&s_visit[par & (BLK - 1)], 1u);
+    } else {
+      if (FENCED) __threadfence();                     // release this subtree's records (agent scope)
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through stores have left this CU
+      arrived = atomicAdd(&visit[par], 1u);
+    }
     if (arrived == 0) break;                           // the sibling's thread will finish this node
-    if (FENCED) __threadfence();                       // acquire the sibling's record
     const int c0 = child[2 * (size_t)par + 0], c1 = child[2 * (size_t)par + 1];
     const int sib = (c0 == cur) ? c1 : c0;
     V3 smn, smx;
-    load_box<FENCED>(nodes, sib, smn, smx);
+    if (local) {
+      __threadfence_block();
+      const int sslot = (sib >= first_leaf) ? ((sib - first_leaf) & (BLK - 1)) : (BLK + (sib & (BLK - 1)));
+      const float* sb = s_box[sslot];
+      smn = v3(sb[0], sb[1], sb[2]); smx = v3(sb[3], sb[4], sb[5]);
+    } else {
+      if (FENCED) __threadfence();                     // acquire the sibling's record
+      load_box<FENCED>(nodes, sib, smn, smx);
+    }
+    {                                                  // 64-byte two-child record of `par`, the statements of k_pack_wide
+      const bool cur0 = (c0 == cur);
+      const V3 a_mn = cur0 ? mn : smn, a_mx = cur0 ? mx : smx, b_mn = cur0 ? smn : mn, b_mx = cur0 ? smx : mx;
+      const uint32_t r0 = (c0 >= first_leaf) ? (0x80000000u | (uint32_t)(c0 - first_leaf)) : (uint32_t)c0;
+      const uint32_t r1 = (c1 >= first_leaf) ? (0x80000000u | (uint32_t)(c1 - first_leaf)) : (uint32_t)c1;
+      wide[4 * (size_t)par + 0] = make_float4(a_mn.x, a_mn.y, a_mn.z, __uint_as_float(r0));
+      wide[4 * (size_t)par + 1] = make_float4(a_mx.x, a_mx.y, a_mx.z, __uint_as_float(r1));
+      wide[4 * (size_t)par + 2] = make_float4(b_mn.x, b_mn.y, b_mn.z, 0.0f);
+      wide[4 * (size_t)par + 3] = make_float4(b_mx.x, b_mx.y, b_mx.z, 0.0f);
+    }
     mn = v3(fminf(mn.x, smn.x), fminf(mn.y, smn.y), fminf(mn.z, smn.z));
     mx = v3(fmaxf(mx.x, smx.x), fmaxf(mx.y, smx.y), fmaxf(mx.z, smx.z));
-    store_node<FENCED>(nodes, par, mn, enc_index(v2, (uint32_t)c0), mx, enc_index(v2, (uint32_t)c1));   // v1: indices as f32 values (F11)
+    pe = parent[par];
+    store_node<FENCED>(nodes, par, mn, enc_index(v2, (uint32_t)c0), mx, enc_index(v2, (uint32_t)c1),   // v1: indices as f32 values (F11)
+                       pe >= 0 && !(pe & PARENT_LOCAL));
     cur = par;
+    cur_slot = BLK + (par & (BLK - 1));              // only meaningful while the climb stays local (ranges nest)
   }
 }
 
@@ -399,7 +466,7 @@ __global__ __launch_bounds__(BLK) void k_refit_verify(const float* __restrict__ 
   const int c0 = child[2 * (size_t)i + 0], c1 = child[2 * (size_t)i + 1];
   const float4 a = nd[2 * (size_t)i], b = nd[2 * (size_t)i + 1];
   const float4 a0 = nd[2 * (size_t)c0], b0 = nd[2 * (size_t)c0 + 1], a1 = nd[2 * (size_t)c1], b1 = nd[2 * (size_t)c1 + 1];
-  bool ok = (visit[i] == 2u) && !dec_is_leaf(v2, b.w) && (dec_index(v2, a.w) == c0) && (dec_index(v2, b.w) == c1);
+  bool ok = !dec_is_leaf(v2, b.w) && (dec_index(v2, a.w) == c0) && (dec_index(v2, b.w) == c1);
   ok = ok && a.x == fminf(a0.x, a1.x) && a.y == fminf(a0.y, a1.y) && a.z == fminf(a0.z, a1.z);
   ok = ok && b.x == fmaxf(b0.x, b1.x) && b.y == fmaxf(b0.y, b1.y) && b.z == fmaxf(b0.z, b1.z);
   if (!ok) atomicOr(err, 8u);
@@ -453,10 +520,11 @@ __global__ __launch_bounds__(BLK) void k_pack_tris(const float* __restrict__ tri
 uint32_t rt_sort_tile_count(uint32_t n) { return (n + SORT_TILE - 1) / SORT_TILE; }
 size_t rt_sort_status_words(uint32_t n) { return (size_t)4 * rt_sort_tile_count(n) * RADIX; }
 
+uint32_t rt_bounds_words() { return 6u * 2048u; }   // grid_for's block cap x 6 partials
 void rt_launch_bounds(const RtBuildBuffers& b, hipStream_t s) {
-  hipLaunchKernelGGL(k_bounds_init, dim3(1), dim3(64), 0, s, b.bounds_enc);
-  hipLaunchKernelGGL(k_bounds, dim3(grid_for(b.n_tri, BLK)), dim3(BLK), 0, s, b.pos, b.vidx, b.n_tri, b.bounds_enc);
-  hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(64), 0, s, b.bounds_enc, b.bounds_f);
+  const int g = grid_for(b.n_tri, BLK);
+  hipLaunchKernelGGL(k_bounds, dim3(g), dim3(BLK), 0, s, b.pos, b.vidx, b.n_tri, b.bounds_enc);
+  hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(384), 0, s, b.bounds_enc, (uint32_t)g, b.bounds_f);
 }
 
 void rt_launch_morton(const RtBuildBuffers& b, hipStream_t s) {
@@ -486,15 +554,16 @@ void rt_launch_karras(const RtBuildBuffers& b, hipStream_t s) {
   hipLaunchKernelGGL(k_karras, dim3((n_int + BLK - 1) / BLK), dim3(BLK), 0, s, b.keys_a, b.n_tri, b.child, b.parent);
 }
 
-void rt_launch_refit(const RtBuildBuffers& b, float* nodes, float* tri_pos, float* tri_nor, bool fenced, bool v2, hipStream_t s) {
+void rt_launch_refit(const RtBuildBuffers& b, float* nodes, float* tri_pos, float* tri_nor, float4* wide, float4* tri_pre,
+                     int leaf_shift, bool fenced, bool v2, hipStream_t s) {
   if (b.n_tri > 1) (void)hipMemsetAsync(b.visit, 0, sizeof(uint32_t) * (b.n_tri - 1), s);
   const dim3 g((b.n_tri + BLK - 1) / BLK), blk(BLK);
   if (fenced)
     hipLaunchKernelGGL(k_refit<true>, g, blk, 0, s, b.pos, b.nor, b.vidx, b.nidx, b.vals_a, b.n_tri, b.child, b.parent, b.visit,
-                       nodes, tri_pos, tri_nor, v2);
+                       nodes, tri_pos, tri_nor, wide, tri_pre, leaf_shift, v2);
   else
     hipLaunchKernelGGL(k_refit<false>, g, blk, 0, s, b.pos, b.nor, b.vidx, b.nidx, b.vals_a, b.n_tri, b.child, b.parent, b.visit,
-                       nodes, tri_pos, tri_nor, v2);
+                       nodes, tri_pos, tri_nor, wide, tri_pre, leaf_shift, v2);
   if (b.n_tri > 1)   // sets bit 8 of err_flag on any inconsistency
     hipLaunchKernelGGL(k_refit_verify, dim3((b.n_tri - 1 + BLK - 1) / BLK), blk, 0, s, nodes, b.n_tri, b.child, b.visit, b.err_flag, v2);
 }

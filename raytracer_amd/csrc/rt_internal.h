@@ -78,7 +78,7 @@ struct RtRenderParams {
 struct RtBuildBuffers {
   const float* pos; const float* nor; const uint32_t* vidx; const uint32_t* nidx;
   uint32_t n_tri;
-  uint32_t* bounds_enc;     // [6] ordered-uint min.xyz / max.xyz
+  uint32_t* bounds_enc;     // [rt_bounds_words()] per-block ordered-uint partials: min.xyz / max.xyz
   float*    bounds_f;       // [8] `Bounds` uniform: min.xyz,0, invExtent.xyz,0 (morton_compute.wgsl:3-6)
   uint32_t* codes;          // [T] unsorted Morton codes
   uint32_t* keys_a; uint32_t* keys_b;     // sort ping-pong
@@ -92,13 +92,16 @@ struct RtBuildBuffers {
   uint32_t* visit;          // [T-1] refit arrival counters
   uint32_t  n_sort_tiles;
 };
+uint32_t rt_bounds_words();
 uint32_t rt_sort_tile_count(uint32_t n);
 size_t   rt_sort_status_words(uint32_t n);
 void rt_launch_bounds(const RtBuildBuffers& b, hipStream_t s);
 void rt_launch_morton(const RtBuildBuffers& b, hipStream_t s);
 void rt_launch_sort(const RtBuildBuffers& b, hipStream_t s);      // result in keys_a / vals_a
 void rt_launch_karras(const RtBuildBuffers& b, hipStream_t s);
-void rt_launch_refit(const RtBuildBuffers& b, float* nodes, float* tri_pos, float* tri_nor, bool fenced, bool v2, hipStream_t s);
+// also writes the traversal layout (wide, tri_pre) from the values it already holds: builds need no pack pass
+void rt_launch_refit(const RtBuildBuffers& b, float* nodes, float* tri_pos, float* tri_nor, float4* wide, float4* tri_pre,
+                     int leaf_shift, bool fenced, bool v2, hipStream_t s);
 // derive the traversal layout from the interchange buffers; writes the root ref / error bits
 void rt_launch_pack_impl(const RtBvhDev& bvh, uint32_t* d_root_ref, uint32_t* d_err, hipStream_t s);
 
