@@ -51,7 +51,7 @@ struct rt_ctx {
 
   // build scratch
   DevBuf<uint32_t> bounds_enc, codes, keys_a, keys_b, vals_a, vals_b, hist, tile_status, tile_counter, visit, words;
-  DevBuf<float> bounds_f;
+  DevBuf<float> bounds_f, centroids;
   DevBuf<int32_t> child, parent;
   bool built = false;      // codes / order valid
   uint32_t refit_fallbacks = 0;
@@ -210,7 +210,7 @@ extern "C" void rt_destroy(rt_ctx* ctx) {
   ctx->pos.release(); ctx->nor.release(); ctx->vidx.release(); ctx->nidx.release();
   ctx->bounds_enc.release(); ctx->codes.release(); ctx->keys_a.release(); ctx->keys_b.release();
   ctx->vals_a.release(); ctx->vals_b.release(); ctx->hist.release(); ctx->tile_status.release();
-  ctx->tile_counter.release(); ctx->visit.release(); ctx->words.release(); ctx->bounds_f.release();
+  ctx->tile_counter.release(); ctx->visit.release(); ctx->words.release(); ctx->bounds_f.release(); ctx->centroids.release();
   ctx->child.release(); ctx->parent.release();
   ctx->own_nodes.release(); ctx->own_tri_pos.release(); ctx->own_tri_nor.release();
   ctx->wide.release(); ctx->tri_pre.release();
@@ -283,7 +283,7 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
   DeviceGuard g(ctx->device);
   JOIN_FRAMES();
   hipStream_t s = ctx->stream;
-  HIPCHK(ctx->bounds_enc.ensure(rt_bounds_words())); HIPCHK(ctx->bounds_f.ensure(8));
+  HIPCHK(ctx->bounds_enc.ensure(rt_bounds_words())); HIPCHK(ctx->bounds_f.ensure(8)); HIPCHK(ctx->centroids.ensure((size_t)T * 3));
   HIPCHK(ctx->codes.ensure(T)); HIPCHK(ctx->keys_a.ensure(T)); HIPCHK(ctx->keys_b.ensure(T));
   HIPCHK(ctx->vals_a.ensure(T)); HIPCHK(ctx->vals_b.ensure(T));
   HIPCHK(ctx->hist.ensure(4 * 256)); HIPCHK(ctx->tile_status.ensure(rt_sort_status_words(T)));
@@ -297,11 +297,17 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
 
   RtBuildBuffers b;
   b.pos = ctx->pos.p; b.nor = ctx->nor.p; b.vidx = ctx->vidx.p; b.nidx = ctx->nidx.p; b.n_tri = T;
-  b.bounds_enc = ctx->bounds_enc.p; b.bounds_f = ctx->bounds_f.p; b.codes = ctx->codes.p;
+  b.bounds_enc = ctx->bounds_enc.p; b.bounds_f = ctx->bounds_f.p; b.centroids = ctx->centroids.p; b.codes = ctx->codes.p;
   b.keys_a = ctx->keys_a.p; b.keys_b = ctx->keys_b.p; b.vals_a = ctx->vals_a.p; b.vals_b = ctx->vals_b.p;
   b.hist = ctx->hist.p; b.tile_status = ctx->tile_status.p; b.tile_counter = ctx->tile_counter.p;
   b.err_flag = ctx->words.p + 2; b.child = ctx->child.p; b.parent = ctx->parent.p; b.visit = ctx->visit.p;
   b.n_sort_tiles = rt_sort_tile_count(T);
+  b.texcoords = nullptr; b.tex_idx = nullptr; b.material_ids = nullptr; b.tri_uv = nullptr;
+  if (ctx->surface_set) {          // surface records into BVH order by the refit, next to triPos / triNor
+    HIPCHK(ctx->tri_uv.ensure((size_t)T * 8));
+    b.texcoords = ctx->texcoords.p; b.tex_idx = ctx->tidx.p; b.material_ids = ctx->surface_has_mat ? ctx->matid.p : nullptr;
+    b.tri_uv = reinterpret_cast<float4*>(ctx->tri_uv.p);
+  }
 
   HIPCHK(hipMemsetAsync(ctx->words.p, 0, 4 * sizeof(uint32_t), s));
   HIPCHK(hipEventRecord(ctx->ev[0], s));
@@ -334,12 +340,7 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
   ctx->bvh.nodes = ctx->own_nodes.p; ctx->bvh.tri_pos = ctx->own_tri_pos.p; ctx->bvh.tri_nor = ctx->own_tri_nor.p;
   ctx->bvh.n_nodes = N; ctx->bvh.n_tri = T; ctx->bvh.owns_interchange = true;
   HIPCHK(hipEventRecord(ctx->ev[6], s));
-  ctx->tri_uv_n = 0;
-  if (ctx->surface_set) {          // surface records into BVH order, next to triPos / triNor (counted in ms_pack)
-    HIPCHK(ctx->tri_uv.ensure((size_t)T * 8));
-    rt_launch_gather_uv(ctx->texcoords.p, ctx->tidx.p, ctx->surface_has_mat ? ctx->matid.p : nullptr, ctx->vals_a.p, T, ctx->tri_uv.p, s);
-    ctx->tri_uv_n = T;
-  }
+  ctx->tri_uv_n = ctx->surface_set ? T : 0;
   int rc = finish_bvh(ctx, /*packed_by_refit=*/true);
   if (rc != RT_OK) return rc;
   HIPCHK(hipEventRecord(ctx->ev[7], s));

@@ -52,11 +52,15 @@ RT_DEV uint32_t wave_max_u32(uint32_t v) {
 // ---------------------------------------------------------------- centroid bounds
 // Two stages, no atomics: every block leaves its six ordered-uint partials in its own slot (2048 blocks x 6 same-address
 // atomicMin/Max serialised at ~26 ns each: 53 of the kernel's 62 us at 1.3 M triangles), one block folds the slots.
+// Also keeps every centroid (12 B/triangle, coalesced) so that k_morton streams them instead of repeating the
+// three-vertex gather through the index buffer (48 B/triangle of scattered reads).
 __global__ __launch_bounds__(BLK) void k_bounds(const float* __restrict__ pos, const uint32_t* __restrict__ vidx,
-                                                uint32_t n_tri, uint32_t* __restrict__ part /* [gridDim.x][6] */) {
+                                                uint32_t n_tri, uint32_t* __restrict__ part /* [gridDim.x][6] */,
+                                                float* __restrict__ centroids /* [3T] */) {
   uint32_t mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u};
   for (uint32_t t = blockIdx.x * BLK + threadIdx.x; t < n_tri; t += gridDim.x * BLK) {
     V3 c = tri_centroid(pos, vidx, t);
+    centroids[3 * (size_t)t + 0] = c.x; centroids[3 * (size_t)t + 1] = c.y; centroids[3 * (size_t)t + 2] = c.z;
     uint32_t e[3] = {f2ord(c.x), f2ord(c.y), f2ord(c.z)};
 #pragma unroll
     for (int k = 0; k < 3; ++k) { mn[k] = min(mn[k], e[k]); mx[k] = max(mx[k], e[k]); }
@@ -100,13 +104,13 @@ __global__ __launch_bounds__(384) void k_bounds_final(const uint32_t* __restrict
 }
 
 // ---------------------------------------------------------------- Morton codes
-__global__ __launch_bounds__(BLK) void k_morton(const float* __restrict__ pos, const uint32_t* __restrict__ vidx,
+__global__ __launch_bounds__(BLK) void k_morton(const float* __restrict__ centroids,
                                                 uint32_t n_tri, const float* __restrict__ bounds_f,
                                                 uint32_t* __restrict__ codes, uint32_t* __restrict__ keys,
                                                 uint32_t* __restrict__ vals) {
   const V3 bmin = v3(bounds_f[0], bounds_f[1], bounds_f[2]), inv = v3(bounds_f[4], bounds_f[5], bounds_f[6]);
   for (uint32_t t = blockIdx.x * BLK + threadIdx.x; t < n_tri; t += gridDim.x * BLK) {
-    V3 ctr = tri_centroid(pos, vidx, t);
+    const V3 ctr = v3(centroids[3 * (size_t)t + 0], centroids[3 * (size_t)t + 1], centroids[3 * (size_t)t + 2]);   // :52, from k_bounds
     V3 nrm = (ctr - bmin) * inv;                                          // :55
     uint32_t code = (expand_bits(quantize10(nrm.x)) << 2) | (expand_bits(quantize10(nrm.y)) << 1) |
                     expand_bits(quantize10(nrm.z));                      // :58-68
@@ -374,6 +378,8 @@ __global__ __launch_bounds__(BLK) void k_refit(const float* __restrict__ pos, co
                                                const int32_t* __restrict__ child, const int32_t* __restrict__ parent,
                                                uint32_t* visit, float* nodes, float* __restrict__ tri_pos,
                                                float* __restrict__ tri_nor, float4* __restrict__ wide, float4* __restrict__ tri_pre,
+                                               const float* __restrict__ texcoords, const uint32_t* __restrict__ tex_idx,
+                                               const int32_t* __restrict__ material_ids, float4* __restrict__ tri_uv,
                                                int leaf_shift, bool v2) {
   __shared__ float s_box[2 * BLK][6];      // [0, BLK): this block's leaves, [BLK, 2 BLK): internal nodes with index in the block's range
   __shared__ uint32_t s_visit[BLK];        // arrival counters of the block-local internal nodes
@@ -399,6 +405,13 @@ __global__ __launch_bounds__(BLK) void k_refit(const float* __restrict__ pos, co
     tri_pre[3 * (size_t)j + 0] = make_float4(p[0].x, p[0].y, p[0].z, ng.x);
     tri_pre[3 * (size_t)j + 1] = make_float4(e1.x, e1.y, e1.z, ng.y);
     tri_pre[3 * (size_t)j + 2] = make_float4(e2.x, e2.y, e2.z, ng.z);
+  }
+  if (texcoords) {                                   // surface record (rtcore.h "material / texture shading"), as k_gather_uv
+    const float2* tc = reinterpret_cast<const float2*>(texcoords);
+    const float2 a = tc[tex_idx[3 * (size_t)ti + 0]], b = tc[tex_idx[3 * (size_t)ti + 1]], c = tc[tex_idx[3 * (size_t)ti + 2]];
+    const int32_t m = material_ids ? material_ids[ti] : -1;
+    tri_uv[2 * (size_t)j + 0] = make_float4(a.x, a.y, b.x, b.y);
+    tri_uv[2 * (size_t)j + 1] = make_float4(c.x, c.y, __uint_as_float((uint32_t)m), 0.0f);
   }
   // true triangle bounds (web/script.js:309-316)
   V3 mn = v3(fminf(fminf(p[0].x, p[1].x), p[2].x), fminf(fminf(p[0].y, p[1].y), p[2].y), fminf(fminf(p[0].z, p[1].z), p[2].z));
@@ -523,12 +536,12 @@ size_t rt_sort_status_words(uint32_t n) { return (size_t)4 * rt_sort_tile_count(
 uint32_t rt_bounds_words() { return 6u * 2048u; }   // grid_for's block cap x 6 partials
 void rt_launch_bounds(const RtBuildBuffers& b, hipStream_t s) {
   const int g = grid_for(b.n_tri, BLK);
-  hipLaunchKernelGGL(k_bounds, dim3(g), dim3(BLK), 0, s, b.pos, b.vidx, b.n_tri, b.bounds_enc);
+  hipLaunchKernelGGL(k_bounds, dim3(g), dim3(BLK), 0, s, b.pos, b.vidx, b.n_tri, b.bounds_enc, b.centroids);
   hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(384), 0, s, b.bounds_enc, (uint32_t)g, b.bounds_f);
 }
 
 void rt_launch_morton(const RtBuildBuffers& b, hipStream_t s) {
-  hipLaunchKernelGGL(k_morton, dim3(grid_for(b.n_tri, BLK)), dim3(BLK), 0, s, b.pos, b.vidx, b.n_tri, b.bounds_f, b.codes,
+  hipLaunchKernelGGL(k_morton, dim3(grid_for(b.n_tri, BLK)), dim3(BLK), 0, s, b.centroids, b.n_tri, b.bounds_f, b.codes,
                      b.keys_a, b.vals_a);
 }
 
@@ -560,10 +573,10 @@ void rt_launch_refit(const RtBuildBuffers& b, float* nodes, float* tri_pos, floa
   const dim3 g((b.n_tri + BLK - 1) / BLK), blk(BLK);
   if (fenced)
     hipLaunchKernelGGL(k_refit<true>, g, blk, 0, s, b.pos, b.nor, b.vidx, b.nidx, b.vals_a, b.n_tri, b.child, b.parent, b.visit,
-                       nodes, tri_pos, tri_nor, wide, tri_pre, leaf_shift, v2);
+                       nodes, tri_pos, tri_nor, wide, tri_pre, b.texcoords, b.tex_idx, b.material_ids, b.tri_uv, leaf_shift, v2);
   else
     hipLaunchKernelGGL(k_refit<false>, g, blk, 0, s, b.pos, b.nor, b.vidx, b.nidx, b.vals_a, b.n_tri, b.child, b.parent, b.visit,
-                       nodes, tri_pos, tri_nor, wide, tri_pre, leaf_shift, v2);
+                       nodes, tri_pos, tri_nor, wide, tri_pre, b.texcoords, b.tex_idx, b.material_ids, b.tri_uv, leaf_shift, v2);
   if (b.n_tri > 1)   // sets bit 8 of err_flag on any inconsistency
     hipLaunchKernelGGL(k_refit_verify, dim3((b.n_tri - 1 + BLK - 1) / BLK), blk, 0, s, nodes, b.n_tri, b.child, b.visit, b.err_flag, v2);
 }

@@ -80,6 +80,7 @@ struct RtBuildBuffers {
   uint32_t n_tri;
   uint32_t* bounds_enc;     // [rt_bounds_words()] per-block ordered-uint partials: min.xyz / max.xyz
   float*    bounds_f;       // [8] `Bounds` uniform: min.xyz,0, invExtent.xyz,0 (morton_compute.wgsl:3-6)
+  float*    centroids;      // [3T] (p0 + p1 + p2) / 3 per input triangle, k_bounds -> k_morton
   uint32_t* codes;          // [T] unsorted Morton codes
   uint32_t* keys_a; uint32_t* keys_b;     // sort ping-pong
   uint32_t* vals_a; uint32_t* vals_b;
@@ -91,6 +92,8 @@ struct RtBuildBuffers {
   int32_t*  parent;         // [2T-1]
   uint32_t* visit;          // [T-1] refit arrival counters
   uint32_t  n_sort_tiles;
+  // optional surface inputs (NULL texcoords = none): the refit also writes the BVH-order records tri_uv [2T float4]
+  const float* texcoords; const uint32_t* tex_idx; const int32_t* material_ids; float4* tri_uv;
 };
 uint32_t rt_bounds_words();
 uint32_t rt_sort_tile_count(uint32_t n);
