@@ -257,6 +257,9 @@ extern "C" int rt_set_mesh(rt_ctx* ctx, const float* positions, uint32_t n_vert,
   if (n_tri > (1u << 30)) return ctx->fail(RT_ERR_LIMIT, "rt_set_mesh: more than 2^30 triangles");
   for (size_t i = 0; i < (size_t)n_tri * 3; ++i)   // a wild index would fault the GPU: check on the host
     if (vert_idx[i] >= n_vert || nor_idx[i] >= n_nor) return ctx->fail(RT_ERR_INVALID, "rt_set_mesh: index out of range");
+  // NaN / Inf positions have no defined Morton code or box order (WGSL leaves clamp / min / max of NaN open): out of contract
+  for (size_t i = 0; i < (size_t)n_vert * 3; ++i)
+    if (!(positions[i] - positions[i] == 0.0f)) return ctx->fail(RT_ERR_INVALID, "rt_set_mesh: non-finite vertex position");
   DeviceGuard g(ctx->device);
   JOIN_FRAMES();
   HIPCHK(ctx->pos.ensure((size_t)n_vert * 3));

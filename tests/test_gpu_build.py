@@ -51,6 +51,31 @@ def test_random_soups(gpu_ctx, oracle, n_tri, seed, quantum):
     _check_build(gpu_ctx, oracle, random_soup(n_tri, seed, quantum))
 
 
+@pytest.mark.parametrize("n_tri", [255, 256, 257, 511, 512, 513, 1023, 1025, 65537])
+def test_refit_block_boundaries(gpu_ctx, oracle, n_tri):
+    """k_refit climbs inside 256-leaf blocks through LDS and across them through HBM: sizes around the block size."""
+    _check_build(gpu_ctx, oracle, random_soup(n_tri, 100 + n_tri % 97, 3 if n_tri % 2 else None))
+
+
+def test_degenerate_geometry(gpu_ctx, oracle, rt):
+    """Zero-area and coincident triangles, a flat (zero-extent) axis, signed zeros, huge and denormal coordinates."""
+    rng = np.random.default_rng(12)
+    pts = rng.random((600, 3)).astype(np.float32)
+    pts[:, 2] = 0.0                                    # flat in z: invExtent.z = 0 (SURVEY §8a-5)
+    pts[::7, 0] = -0.0
+    pts[5::11] *= np.float32(1e-41)                    # denormals are kept (no flush to zero)
+    idx = rng.integers(0, 600, (1500, 3)).astype(np.uint32)
+    idx[:200, 1] = idx[:200, 0]                        # zero-area triangles
+    idx[200:400] = idx[200]                            # 200 copies of one triangle: equal codes, index tie-break all the way
+    nor = np.float32([[0, 0, 1]])
+    m = rt.Mesh(pts, nor, idx.reshape(-1), np.zeros(4500, np.uint32))
+    _check_build(gpu_ctx, oracle, m)
+    big = rt.Mesh((pts * np.float32(1e30)).astype(np.float32), nor, idx.reshape(-1), np.zeros(4500, np.uint32))
+    _check_build(gpu_ctx, oracle, big)
+    same = rt.Mesh(np.float32([[1, 2, 3]] * 3), nor, np.zeros(3 * 300, np.uint32), np.zeros(900, np.uint32))   # every centroid identical
+    _check_build(gpu_ctx, oracle, same)
+
+
 def test_s70k(gpu_ctx, oracle):
     from raytracer_amd import scenes
     st = _check_build(gpu_ctx, oracle, scenes.s70k())
@@ -93,3 +118,10 @@ def test_errors(gpu_ctx, rt):
     with pytest.raises(rt.RtError):
         bad = rt.Mesh(np.float32([[0, 0, 0]]), np.float32([[0, 0, 1]]), np.uint32([0, 1, 2]), np.uint32([0, 0, 0]))
         gpu_ctx.set_mesh(bad)     # index out of range must be rejected on the host, never reach the GPU
+    for poison in (np.nan, np.inf, -np.inf):
+        with pytest.raises(rt.RtError):
+            gpu_ctx.set_mesh(rt.Mesh(np.float32([[0, 0, 0], [1, poison, 0], [0, 1, 0]]), np.float32([[0, 0, 1]]), np.uint32([0, 1, 2]),
+                                     np.uint32([0, 0, 0])))
+    with pytest.raises(rt.RtError):
+        gpu_ctx.build_lbvh() if False else gpu_ctx.set_mesh(rt.Mesh(np.zeros((0, 3), np.float32), np.float32([[0, 0, 1]]), np.zeros(0, np.uint32),
+                                                                    np.zeros(0, np.uint32)))   # empty mesh
