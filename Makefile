@@ -5,7 +5,7 @@ HIPCC     ?= /opt/rocm/bin/hipcc
 ARCH      ?= gfx950
 # strict IEEE f32 on the device: no contraction, correctly rounded div/sqrt, denormals kept
 HIPFLAGS  ?= --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math \
-             -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -Wall -Wno-unused-function
+             -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -Wall -Wno-unused-function $(EXTRA)
 CSRC      := raytracer_amd/csrc
 LIB       := raytracer_amd/lib/librtcore.so
 OBJS      := build/rt_api.o build/rt_build.o build/rt_trace.o build/rt_scene.o

@@ -266,6 +266,13 @@ int rt_bvh_adopt_device(rt_ctx* ctx, const rt_bvh_view* view);
 int rt_profile_begin(rt_ctx* ctx);
 int rt_profile_end(rt_ctx* ctx, float* ms_frame_avg, float* ms_traverse_avg, uint32_t* n_frames);
 
+/* Frame-coherent scheduling (on by default; no counterpart in the reference).  Every frame leaves one cost class per
+ * pixel (how many traversal steps its rays took); the next frame of the same shape traces last frame's long pixels
+ * first and packs pixels of one class into the same wavefronts.  The classes are hints: they change the ORDER in which
+ * pixels are traced, never a pixel, a counter or a hit id — a frame with stale or no hints (first frame, new resolution,
+ * new BVH, camera cut) is correct and merely runs at the unhinted speed.  Off: every frame is traced in tile order. */
+int rt_set_coherent_scheduling(rt_ctx* ctx, int on);
+
 /* Frames in flight (no counterpart in the reference, whose rAF loop submits one frame at a time, script.js:865-974).
  * A persistent traversal launch ends with a tail in which a few waves finish their last pixels (each pixel is a
  * chain of dependent node fetches), and small frames - a 1/8 stripe share of a 4K frame - are mostly tail.

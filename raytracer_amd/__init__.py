@@ -297,6 +297,10 @@ class Context:
         v = _abi.BvhView(d_nodes, 32 * n_nodes, d_tri_pos, 48 * n_tri, d_tri_nor, 48 * n_tri, n_nodes, n_tri)
         self._chk(_L.rt_bvh_adopt_device(self._h, C.byref(v)))
 
+    def set_coherent_scheduling(self, on):
+        """Frame-coherent scheduling hints (rtcore.h): on by default; results never depend on it."""
+        self._chk(_L.rt_set_coherent_scheduling(self._h, 1 if on else 0))
+
     def set_frames_in_flight(self, n):
         """1 (default): frames run in order on stream(); 2: asynchronous frames alternate between two frame streams."""
         self._chk(_L.rt_set_frames_in_flight(self._h, n))

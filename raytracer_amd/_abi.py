@@ -28,7 +28,7 @@ SYMBOLS = [
     "rt_bvh_view_get", "rt_bvh_export_device", "rt_bvh_adopt_device", "rt_synchronize", "rt_stream",
     "rt_profile_begin", "rt_profile_end", "rt_set_node_encoding", "rt_get_node_encoding",
     "rt_set_surface", "rt_get_tri_uv", "rt_set_tri_uv", "rt_set_materials", "rt_set_texture", "rt_tri_uv_device",
-    "rt_adopt_tri_uv_device", "rt_tri_uv_export_device", "rt_set_frames_in_flight", "rt_frames_join",
+    "rt_adopt_tri_uv_device", "rt_tri_uv_export_device", "rt_set_frames_in_flight", "rt_frames_join", "rt_set_coherent_scheduling",
 ]
 
 
@@ -157,7 +157,8 @@ def load():
         "rt_adopt_tri_uv_device": (C.c_int, [vp, vp, u32]),
         "rt_tri_uv_export_device": (C.c_int, [vp, vp, C.c_uint64]),
         "rt_set_frames_in_flight": (C.c_int, [vp, C.c_int]),
-        "rt_frames_join": (C.c_int, [vp, vp]),
+        "rt_frames_join": (C.c_int, [vp, C.c_int]),
+        "rt_set_coherent_scheduling": (C.c_int, [vp, C.c_int]),
     }
     for name in SYMBOLS:
         fn = getattr(L, name)          # AttributeError here = the library does not export a declared symbol

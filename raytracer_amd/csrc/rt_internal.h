@@ -66,10 +66,14 @@ struct RtRenderParams {
   float*    hit_t;
   uint32_t* shard_heads;           // [rt_shard_words()] phase-B queue heads, one per 128-byte line; zeroed before launch
   uint32_t shard_stride;           // words between shard heads
-  unsigned long long* masks;       // [n_tiles] per-tile ballot of pixels whose primary ray enters the root box
-  uint32_t* block_total;           // [rt_cull_blocks(n_tiles)]
-  uint32_t* list;                  // [local_rows*width] compacted pixel ids (phase A -> phase B)
+  unsigned long long* masks;       // [3 * n_tiles] per tile and cost class: ballot of pixels whose primary ray enters the root box
+  uint32_t* block_total;           // [3 * rt_cull_blocks(n_tiles)] per block and cost class
+  uint32_t* list;                  // [local_rows*width] compacted pixel ids (phase A -> phase B): hot class first
   uint32_t* list_count;            // written by k_compact
+  // Frame-coherent scheduling hints (never results): cost class of every pixel as measured by the previous frame
+  // (0 = cheap or unknown, 1 = normal, 2 = hot), read by k_cull, rewritten by k_render.  NULL = no hints.
+  uint8_t*  pix_class;             // [local_rows*width]
+  uint32_t  class_t1, class_t2;    // traversal steps: class = (steps >= t1) + (steps >= t2)
   unsigned long long* stats;       // [8]: rays_primary, rays_shadow, rays_bounce, box, tri, hitupd, pixels, drops
   unsigned long long* stats_partial;   // [rt_render_grid()*8] per-block partials of phase B
 };

@@ -15,6 +15,7 @@
 // guard that silently drops the far child (F9), strict `<` closest-hit update, front-face
 // only Möller–Trumbore, child0-chain shadow walk (F8), shared RNG sequence (F7).
 #include <cmath>
+#include <cstdlib>
 
 #include "rt_device.h"
 #include "rt_internal.h"
@@ -26,7 +27,7 @@ constexpr uint32_t REF_DONE = 0xFFFFFFFFu;
 constexpr float TWO_PI_F = 6.283185307179586f;
 
 struct Work { uint32_t box, tri, hit, drops; };
-struct Hit { float t; uint32_t tri; float u, v; };
+struct Hit { float t; uint32_t tri; float u, v; uint32_t steps; };   // steps: loop iterations of the traversal (scheduling hint only)
 
 struct Scene {
   const float4* nodes;     // interchange records, 2 x float4 per node
@@ -133,7 +134,7 @@ RT_DEV Hit closest_wide(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Wor
       if (leaf_j >= count) { leaf_j = 0; cur = pop(); }
     }
   }
-  Hit h; h.t = bestT; h.tri = bestTri; h.u = bu; h.v = bv;
+  Hit h; h.t = bestT; h.tri = bestTri; h.u = bu; h.v = bv; h.steps = S.step_budget - budget;
   return h;
 }
 
@@ -229,7 +230,7 @@ RT_DEV Hit closest_aos(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Work
       if (sp > 0) { sp -= 1; cur = (int)S.stk_ref[sp * TBLK]; } else break;
     }
   }
-  Hit h; h.t = bestT; h.tri = bestTri; h.u = bu; h.v = bv;
+  Hit h; h.t = bestT; h.tri = bestTri; h.u = bu; h.v = bv; h.steps = 2u * S.step_budget - budget;
   return h;
 }
 
@@ -364,7 +365,7 @@ RT_DEV V3 mat_mul3(const float* m, V3 v) {
 }
 RT_DEV uint32_t unorm8(float c) { return sat_u32(floorf(fminf(fmaxf(c, 0.0f), 1.0f) * 255.0f + 0.5f)); }
 
-struct PixelOut { uint32_t rgba; uint32_t tri; float t; };
+struct PixelOut { uint32_t rgba; uint32_t tri; float t; uint32_t cost; };   // cost: traversal steps of all closest-hit rays of the pixel
 
 struct PrimaryRay { V3 ro, rd, inv, light; uint32_t pixelIndex; };
 
@@ -397,7 +398,7 @@ RT_DEV PixelOut shade_pixel(const Scene& S, const Shade& sh, const float* U, uin
   PixelOut out;
   R.primary += 1;
   const Hit hit0 = closest<LAYOUT, COUNT>(S, ro_os, rd_os, pr.inv, 1e20f, W);
-  out.tri = hit0.tri; out.t = hit0.t;
+  out.tri = hit0.tri; out.t = hit0.t; out.cost = hit0.steps;
   if (hit0.t >= 1e19f) { out.rgba = 0xFF000000u; out.tri = 0xFFFFFFFFu; return out; }   // (0,0,0,1)
 
   const V3 hit_pos = fma3(rd_os, hit0.t, ro_os);
@@ -418,6 +419,7 @@ RT_DEV PixelOut shade_pixel(const Scene& S, const Shade& sh, const float* U, uin
         const V3 dir = sample_hemisphere(n_b, s1, s2);
         R.bounce += 1;
         const Hit hb = closest<LAYOUT, COUNT>(S, ro_b, dir, rcp3(dir), 1e20f, W);
+        out.cost += hb.steps;
         if (hb.t >= 1e19f) break;
         const V3 pB = fma3(dir, hb.t, ro_b);
         const V3 nB = hit_normal(S, hb);
@@ -488,16 +490,27 @@ __global__ void k_stats_final(const RtRenderParams p, uint32_t n_blocks, uint32_
 // ---- frame pipeline: k_cull -> k_compact -> k_render (persistent) -> k_stats_final -------------
 // Same-address atomics serialise at ~26 ns each on this part (measured: 10 k list appends cost
 // 267 us of a 325 us launch), so the compaction is atomic-free and the phase-B queue is sharded.
+//
+// Frame-coherent scheduling.  A 64-pixel chunk costs what its slowest lane costs, and pixel costs are spread over two
+// orders of magnitude (cfg 3: a ray that only crosses the root box takes ~6 traversal steps, a hit ~40, a grazing ray up to
+// 185).  With the pixel list in plain tile order the queue was empty at 361 us of a 523 us launch: the rest was a tail of
+// few long chunks, and silhouette tiles kept 60 cheap lanes idle behind 4 long ones.  The previous frame measured every
+// pixel (k_render stores a cost class per pixel); the next frame's k_cull / k_compact build the list as
+// [hot | normal | cheap]: long rays share waves, start first, and the tail of the launch is made of cheap chunks.  The
+// classes are hints only: they decide the ORDER pixels are traced in, never a result, and a frame without hints
+// (first frame, resized image) is simply traced in tile order.
 constexpr int CULL_TPB = 64;          // tiles per k_cull / k_compact block: 16 rounds x 4 waves
-constexpr int N_SHARD = 64;           // phase-B queue shards, one 128-byte line each
+constexpr int N_SHARD = 64;           // phase-B queue shards, one 128-byte line of queue state each
 constexpr int SHARD_STRIDE = 32;      // uint32 words between shard heads: one 128-byte line each
+constexpr int N_CLASS = 3;
 static int shard_stride_words() { return SHARD_STRIDE; }
+
 
 // Phase A1 — cull.  One lane per pixel of an 8x8 tile.  A primary ray that misses the root box
 // (compute.wgsl:275 on node 0) can never hit anything: its pixel is final here ((0,0,0,1),
-// compute.wgsl:365-367).  The ballot of the remaining lanes is the tile's mask.
+// compute.wgsl:365-367).  The ballots of the remaining lanes, split by last frame's cost class, are the tile's masks.
 __global__ __launch_bounds__(TBLK) void k_cull(const RtRenderParams p) {
-  __shared__ uint32_t s_cnt[CULL_TPB];
+  __shared__ uint32_t s_cnt[N_CLASS][CULL_TPB];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float4 ra = reinterpret_cast<const float4*>(p.nodes)[0], rb = reinterpret_cast<const float4*>(p.nodes)[1];
   if (blockIdx.x == 0)   // phase-B queue heads start at zero (k_render runs two launches later)
@@ -506,12 +519,13 @@ __global__ __launch_bounds__(TBLK) void k_cull(const RtRenderParams p) {
   for (int r = 0; r < CULL_TPB / (TBLK / 64); ++r) {
     const int k = r * (TBLK / 64) + w;                       // the 4 waves of a block work on 4 adjacent tiles
     const uint32_t tile = blockIdx.x * CULL_TPB + (uint32_t)k;
-    unsigned long long m = 0ull;
+    unsigned long long m[N_CLASS] = {0ull, 0ull, 0ull};
     if (tile < p.n_tiles) {
       const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
       const uint32_t x = tx * 8u + (uint32_t)(lane & 7), lrow = ty * 8u + (uint32_t)(lane >> 3);
       const uint32_t y = local_to_global_row(p, lrow);
       bool enters = false;
+      uint32_t cls = 0;
       if (x < p.width && lrow < p.local_rows && y < p.height) {
         const uint32_t idx = lrow * p.width + x;
         // tiles wholly outside the conservative screen rectangle of the root box need no ray (wave-uniform test:
@@ -527,72 +541,111 @@ __global__ __launch_bounds__(TBLK) void k_cull(const RtRenderParams p) {
           if (p.rgba8) reinterpret_cast<uint32_t*>(p.rgba8)[idx] = 0xFF000000u;
           if (p.hit_tri) p.hit_tri[idx] = 0xFFFFFFFFu;
           if (p.hit_t) p.hit_t[idx] = 1e20f;
+        } else if (p.pix_class) {
+          cls = p.pix_class[idx];                             // last frame's hint; anything else than 1 / 2 counts as 0
         }
       }
-      m = __ballot(enters);
-      if (lane == 0) p.masks[tile] = m;
+      m[2] = __ballot(enters && cls == 2u);
+      m[1] = __ballot(enters && cls == 1u);
+      m[0] = __ballot(enters && cls != 1u && cls != 2u);
+      if (lane < N_CLASS) p.masks[(size_t)tile * N_CLASS + lane] = (lane == 0) ? m[0] : (lane == 1) ? m[1] : m[2];
     }
-    if (lane == 0) s_cnt[k] = (uint32_t)__popcll(m);
+    if (lane < N_CLASS) s_cnt[lane][k] = (uint32_t)__popcll((lane == 0) ? m[0] : (lane == 1) ? m[1] : m[2]);
   }
   __syncthreads();
-  if (w == 0) {
-    const uint32_t tot = wave_sum_u32(s_cnt[lane]);
-    if (lane == 0) p.block_total[blockIdx.x] = tot;
+  if (w < N_CLASS) {
+    const uint32_t tot = wave_sum_u32(s_cnt[w][lane]);
+    if (lane == 0) p.block_total[(size_t)blockIdx.x * N_CLASS + w] = tot;
   }
 }
 
-// Phase A2 — compact.  Block b owns the same 64 tiles as in k_cull; its list offset is the sum
-// of the totals of the blocks before it (a few KB read per block), the in-block offsets come
-// from a wave scan of the 64 tile popcounts.  Deterministic list order: tile-major.
+// Phase A2 — compact.  Block b owns the same 64 tiles as in k_cull.  List layout: class-major (hot, normal, cheap); inside
+// a class block-major, tile-major, lane order.  Every offset is a sum of k_cull's per-block per-class totals (a few KB
+// read per block) plus a wave scan of the block's 64 tile popcounts: atomic-free and deterministic.
 __global__ __launch_bounds__(TBLK) void k_compact(const RtRenderParams p) {
-  __shared__ uint32_t s_red[TBLK / 64];
-  __shared__ uint32_t s_pref[CULL_TPB];
-  __shared__ uint32_t s_tot;
+  __shared__ uint32_t s_red[TBLK / 64][2 * N_CLASS];
+  __shared__ uint32_t s_pref[N_CLASS][CULL_TPB];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  uint32_t part = 0;
-  for (uint32_t i = threadIdx.x; i < blockIdx.x; i += TBLK) part += p.block_total[i];
-  part = wave_sum_u32(part);
-  if (lane == 0) s_red[w] = part;
-  if (w == 0) {
-    const uint32_t tile = blockIdx.x * CULL_TPB + (uint32_t)lane;
-    const uint32_t c = (tile < p.n_tiles) ? (uint32_t)__popcll(p.masks[tile]) : 0u;
+  const uint32_t n_blocks = gridDim.x, me = blockIdx.x;
+  uint32_t all[N_CLASS] = {0, 0, 0}, mine[N_CLASS] = {0, 0, 0};     // class totals of the frame / of the blocks before me
+  for (uint32_t i = threadIdx.x; i < n_blocks; i += TBLK) {
+#pragma unroll
+    for (int c = 0; c < N_CLASS; ++c) {
+      const uint32_t t = p.block_total[(size_t)i * N_CLASS + c];
+      all[c] += t;
+      if (i < me) mine[c] += t;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < N_CLASS; ++c) {
+    const uint32_t a = wave_sum_u32(all[c]), m = wave_sum_u32(mine[c]);
+    if (lane == 0) { s_red[w][c] = a; s_red[w][N_CLASS + c] = m; }
+  }
+  if (w < N_CLASS) {                                          // wave c scans the block's 64 tile counts of class c
+    const uint32_t tile = me * CULL_TPB + (uint32_t)lane;
+    const uint32_t c = (tile < p.n_tiles) ? (uint32_t)__popcll(p.masks[(size_t)tile * N_CLASS + w]) : 0u;
     uint32_t inc = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const uint32_t t = (uint32_t)__shfl_up((int)inc, o);
       if (lane >= o) inc += t;
     }
-    s_pref[lane] = inc - c;
-    if (lane == 63) s_tot = inc;
+    s_pref[w][lane] = inc - c;
   }
   __syncthreads();
-  uint32_t off = 0;
+  uint32_t tot[2 * N_CLASS];
 #pragma unroll
-  for (int i = 0; i < TBLK / 64; ++i) off += s_red[i];
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *p.list_count = off + s_tot;
+  for (int k = 0; k < 2 * N_CLASS; ++k) {
+    tot[k] = 0;
+#pragma unroll
+    for (int i = 0; i < TBLK / 64; ++i) tot[k] += s_red[i][k];
+  }
+  // list order: hot (2), normal (1), cheap / unknown (0)
+  uint32_t base[N_CLASS];
+  base[2] = tot[N_CLASS + 2];
+  base[1] = tot[2] + tot[N_CLASS + 1];
+  base[0] = tot[2] + tot[1] + tot[N_CLASS + 0];
+  if (me == 0 && threadIdx.x == 0) { p.list_count[0] = tot[0] + tot[1] + tot[2]; p.list_count[1] = tot[2]; }   // all, hot
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll 1
   for (int r = 0; r < CULL_TPB / (TBLK / 64); ++r) {
     const int k = r * (TBLK / 64) + w;
-    const uint32_t tile = blockIdx.x * CULL_TPB + (uint32_t)k;
+    const uint32_t tile = me * CULL_TPB + (uint32_t)k;
     if (tile >= p.n_tiles) break;
-    const unsigned long long m = p.masks[tile];
-    if ((m >> lane) & 1ull) {
-      const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
-      const uint32_t x = tx * 8u + (uint32_t)(lane & 7), lrow = ty * 8u + (uint32_t)(lane >> 3);
-      p.list[off + s_pref[k] + (uint32_t)__popcll(m & lt)] = lrow * p.width + x;
+    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const uint32_t x = tx * 8u + (uint32_t)(lane & 7), lrow = ty * 8u + (uint32_t)(lane >> 3);
+#pragma unroll
+    for (int c = 0; c < N_CLASS; ++c) {
+      const unsigned long long m = p.masks[(size_t)tile * N_CLASS + c];
+      if ((m >> lane) & 1ull) p.list[base[c] + s_pref[c][k] + (uint32_t)__popcll(m & lt)] = lrow * p.width + x;
     }
   }
 }
 
 // Phase B — persistent-thread traversal + shading over the compacted pixel list (all 64 lanes
-// carry rays that enter the tree).  The 64-pixel chunks are split into N_SHARD contiguous
-// ranges, each with its own queue head on its own cache line.  A wave drains its home shard
-// (blocks with equal blockIdx % 8 share an XCD and get neighbouring shards = one image region,
+// carry rays that enter the tree).  The list's 64-pixel chunks are dealt to N_SHARD queue shards in groups of SHARD_GROUP
+// consecutive chunks, round-robin, so every shard walks the list front to back (hot -> cheap) and all shards hold the
+// same amount of work; each shard has its own head on its own cache line.  A wave drains its home shard
+// (blocks with equal blockIdx % 8 share an XCD and get neighbouring shards = neighbouring chunk groups,
 // for L2 locality only), then steals from whichever shard a cheap load scan shows non-empty.
+constexpr uint32_t SHARD_GROUP = 8;
+RT_DEV uint32_t shard_chunk(uint32_t shard, uint32_t k) {     // k-th chunk of a shard; increasing in k
+  return ((k / SHARD_GROUP) * N_SHARD + shard) * SHARD_GROUP + (k % SHARD_GROUP);
+}
+#ifdef RT_TIMELINE   // analysis build only (make EXTRA=-DRT_TIMELINE): per-wave start / last-chunk-start / end clocks of k_render
+__device__ unsigned long long g_timeline[4096 * 4][4];
+extern "C" int rt_debug_timeline(unsigned long long* out, size_t n_words) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(unsigned long long) * n_words);
+}
+#endif
+
 template <int LAYOUT, bool COUNT, bool TEX>
 __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
+#ifdef RT_TIMELINE
+  const unsigned long long tl_start = wall_clock64();
+  unsigned long long tl_last = tl_start, tl_chunks = 0;
+#endif
   uint32_t* stk_ref = reinterpret_cast<uint32_t*>(smem);
   float* stk_t = reinterpret_cast<float*>(smem + sizeof(uint32_t) * (size_t)p.max_stack * TBLK);
 
@@ -613,24 +666,24 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
   uint32_t pixels = 0;
   const uint32_t n_list = *p.list_count;                 // written by k_compact (previous launch on this stream)
   const uint32_t n_chunks = (n_list + 63u) / 64u;
-  // lane l looks after shard l: its chunk range [lo, hi)
-  const uint32_t my_lo = (uint32_t)(((unsigned long long)n_chunks * (uint32_t)lane) / N_SHARD);
-  const uint32_t my_hi = (uint32_t)(((unsigned long long)n_chunks * (uint32_t)(lane + 1)) / N_SHARD);
   const uint32_t per_xcd = (gridDim.x + 7u) / 8u;
   int shard = (int)((blockIdx.x & 7u) * (N_SHARD / 8) + ((blockIdx.x >> 3) * (N_SHARD / 8)) / per_xcd) & (N_SHARD - 1);
   for (uint32_t scans = 0; scans <= 4u * N_SHARD; ++scans) {          // every wave reaches the exit: a scan that finds nothing
+    // lane l looks after shard l
     const uint32_t head = __hip_atomic_load(p.shard_heads + (size_t)lane * p.shard_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned long long avail = __ballot(my_lo + head < my_hi);
+    unsigned long long avail = __ballot(shard_chunk((uint32_t)lane, head) < n_chunks);
     if (!avail) break;
     // first non-empty shard at or after `shard` (rotating)
     const unsigned long long rot = (shard == 0) ? avail : ((avail >> shard) | (avail << (64 - shard)));
     shard = (shard + (__ffsll((long long)rot) - 1)) & (N_SHARD - 1);
-    const uint32_t lo = (uint32_t)__shfl((int)my_lo, shard), hi = (uint32_t)__shfl((int)my_hi, shard);
     for (;;) {
       uint32_t h = 0;
       if (lane == 0) h = atomicAdd(p.shard_heads + (size_t)shard * p.shard_stride, 1u);
-      const uint32_t chunk = lo + (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
-      if (chunk >= hi) break;
+      const uint32_t chunk = shard_chunk((uint32_t)shard, (uint32_t)__builtin_amdgcn_readfirstlane((int)h));
+      if (chunk >= n_chunks) break;
+#ifdef RT_TIMELINE
+      tl_last = wall_clock64(); tl_chunks += 1;
+#endif
       const uint32_t li = chunk * 64u + (uint32_t)lane;
       if (li < n_list) {
         const uint32_t idx = p.list[li];
@@ -640,10 +693,17 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
         if (p.rgba8) reinterpret_cast<uint32_t*>(p.rgba8)[idx] = o.rgba;
         if (p.hit_tri) p.hit_tri[idx] = o.tri;
         if (p.hit_t) p.hit_t[idx] = o.t;
+        if (p.pix_class) p.pix_class[idx] = (uint8_t)((o.cost >= p.class_t1 ? 1u : 0u) + (o.cost >= p.class_t2 ? 1u : 0u));
         pixels += 1;
       }
     }
   }
+#ifdef RT_TIMELINE
+  if (lane == 0 && blockIdx.x < 4096) {
+    unsigned long long* t = g_timeline[blockIdx.x * 4 + (threadIdx.x >> 6)];
+    t[0] = tl_start; t[1] = tl_last; t[2] = wall_clock64(); t[3] = tl_chunks;
+  }
+#endif
   flush_stats<COUNT>(p, lane, R, W, pixels);
 }
 
@@ -690,6 +750,7 @@ static uint32_t resident_grid(int n_cu, int max_stack, bool tex) {
                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_render<RT_LAYOUT_WIDE64, true, false>), TBLK, lds);
     if (e != hipSuccess || nb < 1) nb = 2;
     slot = nb > 4 ? 4 : nb;
+    if (const char* e = getenv("RTCORE_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= slot) slot = v; }
   }
   return (uint32_t)n_cu * (uint32_t)slot;
 }

@@ -165,3 +165,32 @@ def test_cull_rectangle_is_conservative(gpu_ctx, oracle, rt, plane_mesh):
             assert st[k] == rst[k], f"view {i} {k}: gpu {st[k]} vs oracle {rst[k]}"
         seen += int((ref["hit_tri"] != 0xFFFFFFFF).any())
     assert seen >= 5
+
+
+def test_coherent_scheduling_changes_order_only(gpu_ctx, oracle, rt, plane_mesh):
+    """Frame-coherent scheduling: frames 2, 3, ... of a view are traced in last frame's cost order (hot pixels first, one
+    class per wavefront).  Outputs and work counters must not depend on it: same view repeated, a camera cut with stale
+    hints, hints switched off, a second resolution — all against the oracle."""
+    ref_b = _scene(gpu_ctx, oracle, plane_mesh)
+    opts = rt.render_opts(mode=rt.MODE_SHADOW, flags=rt.FLAG_COUNT_WORK)
+    views = [dict(PLANE_VIEW), dict(PLANE_VIEW, cam_pos=(0.15, -0.1, 1.1), rot_deg=(-60.0, 20.0, 5.0))]
+    refs = []
+    for v in views:
+        U = rt.make_uniforms(256, 160, **v)
+        refs.append((U,) + oracle.render(ref_b["nodes"], ref_b["tri_pos"], ref_b["tri_nor"], U, mode=1, n_threads=8))
+    try:
+        for on in (True, False, True):
+            gpu_ctx.set_coherent_scheduling(on)
+            for k in (0, 0, 0, 1, 1, 0):                    # repeats build hints; 0 -> 1 -> 0 are cuts with stale hints
+                U, ref, rst = refs[k]
+                out, st = gpu_ctx.render(U, opts)
+                for key in ("hit_tri", "hit_t", "rgba8"):
+                    assert np.array_equal(out[key], ref[key]), (on, k, key)
+                for key in COUNT_KEYS:
+                    assert st[key] == rst[key], (on, k, key)
+            U2 = rt.make_uniforms(97, 65, **views[0])        # another shape: hints are dropped, not reused
+            out, _ = gpu_ctx.render(U2, opts)
+            ref2, _ = oracle.render(ref_b["nodes"], ref_b["tri_pos"], ref_b["tri_nor"], U2, mode=1, n_threads=8)
+            assert np.array_equal(out["rgba8"], ref2["rgba8"]) and np.array_equal(out["hit_tri"], ref2["hit_tri"])
+    finally:
+        gpu_ctx.set_coherent_scheduling(True)
