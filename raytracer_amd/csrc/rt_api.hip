@@ -84,6 +84,7 @@ struct rt_ctx {
   // tail of frame i (few waves left, latency-bound) overlaps the head of frame i+1
   DevBuf<uint8_t> pix_class;                   // frame-coherent scheduling hints (rt_trace.hip), shared by the frame slots
   uint64_t pix_class_key = ~0ull;
+  bool class_partial_reset[2] = {true, true};
   uint32_t bvh_serial = 0;                     // bumped whenever the BVH changes
   bool coherent_scheduling = true;
   int frames_in_flight = 1;
@@ -770,14 +771,17 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
     JOIN_FRAMES();
   }
   HIPCHK(ctx->r_tile_counter[slot].ensure(rt_shard_words() + 32 + 3 * (size_t)cull_blocks));
-  HIPCHK(ctx->r_stats[slot].ensure(8 + (size_t)rt_render_grid(ctx->n_cu) * 8 + 3 * (size_t)p.n_tiles));
+  HIPCHK(ctx->r_stats[slot].ensure(8 + 32 + (size_t)rt_render_grid(ctx->n_cu) * 8 + 3 * (size_t)p.n_tiles));
   HIPCHK(ctx->r_list[slot].ensure((size_t)p.local_rows * p.width));
   p.shard_stride = rt_shard_stride();
+  p.shard_group = 8;
+  if (const char* e = std::getenv("RTCORE_SHARD_GROUP")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) p.shard_group = (uint32_t)v; }
   p.shard_heads = ctx->r_tile_counter[slot].p; p.list_count = ctx->r_tile_counter[slot].p + rt_shard_words();
   p.block_total = ctx->r_tile_counter[slot].p + rt_shard_words() + 32;
   p.list = ctx->r_list[slot].p;
-  p.stats = ctx->r_stats[slot].p; p.stats_partial = ctx->r_stats[slot].p + 8;
-  p.masks = ctx->r_stats[slot].p + 8 + (size_t)rt_render_grid(ctx->n_cu) * 8;
+  p.stats = ctx->r_stats[slot].p; p.stats_partial = ctx->r_stats[slot].p + 8 + 32;
+  p.class_hist = reinterpret_cast<uint32_t*>(ctx->r_stats[slot].p + 8);   // 64 u32
+  p.masks = ctx->r_stats[slot].p + 8 + 32 + (size_t)rt_render_grid(ctx->n_cu) * 8;
   // frame-coherent scheduling hints: one cost class per pixel of this image shape, cleared whenever the shape, the
   // striping or the BVH changes (hints of another view are merely useless, never wrong: they only order the work)
   if (ctx->coherent_scheduling) {
@@ -789,14 +793,22 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
       for (int k = 0; k < 2; ++k) if (ctx->fstream[k]) HIPCHK(hipStreamSynchronize(ctx->fstream[k]));
       HIPCHK(ctx->pix_class.ensure(n_px));
       HIPCHK(hipMemsetAsync(ctx->pix_class.p, 0, n_px, s));
+      ctx->class_partial_reset[0] = ctx->class_partial_reset[1] = true;
       ctx->pix_class_key = key;
+    }
+    if (ctx->class_partial_reset[slot]) {
+      HIPCHK(hipMemsetAsync(p.class_hist, 0, sizeof(uint32_t) * 64, s));
+      ctx->class_partial_reset[slot] = false;
     }
     p.pix_class = ctx->pix_class.p;
     // traversal steps per pixel: a ray that only crosses the root box takes a handful, a hit a few dozen
-    // (cfg 3: ~6 / ~40, grazing rays up to 185).  t2 = 40 measured best (k_render 0.523 -> 0.397 ms; 32: 0.47, 48: 0.41, 64: 0.43).
+    // (cfg 3: ~6 / ~40, grazing rays up to 185).  A fixed t2 is scene-dependent (cfg 3 best at 40 steps: 0.523 -> 0.387 ms, 32: 0.47,
+    // 48: 0.41, 64: 0.43; cfg 5 best at 80), so the hot threshold follows last frame's step histogram instead.
     // PT pixels are a chain of ~50 traversals whatever their class: only hit / miss is separated there.
     p.class_t1 = 16u;
-    p.class_t2 = (opts->mode == RT_MODE_PT) ? 0xFFFFFFFFu : 40u;
+    p.class_t2 = (opts->mode == RT_MODE_PT) ? 0xFFFFFFFFu : 0u;   // 0 = adaptive: the top class_hot_pct % of last frame's non-cheap pixels
+    p.class_hot_pct = 20u;    // measured: 20 / 30 / 40 / 50 % -> k_render 0.394 / 0.415 / 0.394 / 0.451 ms (cfg 3), 3.20 / 3.21 / 3.23 / 3.27 ms (cfg 5)
+    if (const char* e = std::getenv("RTCORE_HOT_PCT")) p.class_hot_pct = (uint32_t)std::atoll(e);
     if (const char* e = std::getenv("RTCORE_T1")) p.class_t1 = (uint32_t)std::atoll(e);
     if (const char* e = std::getenv("RTCORE_T2")) p.class_t2 = (uint32_t)std::atoll(e);
   }

@@ -66,6 +66,7 @@ struct RtRenderParams {
   float*    hit_t;
   uint32_t* shard_heads;           // [rt_shard_words()] phase-B queue heads, one per 128-byte line; zeroed before launch
   uint32_t shard_stride;           // words between shard heads
+  uint32_t shard_group;            // consecutive chunks dealt to one shard at a time (round-robin over the shards)
   unsigned long long* masks;       // [3 * n_tiles] per tile and cost class: ballot of pixels whose primary ray enters the root box
   uint32_t* block_total;           // [3 * rt_cull_blocks(n_tiles)] per block and cost class
   uint32_t* list;                  // [local_rows*width] compacted pixel ids (phase A -> phase B): hot class first
@@ -73,7 +74,10 @@ struct RtRenderParams {
   // Frame-coherent scheduling hints (never results): cost class of every pixel as measured by the previous frame
   // (0 = cheap or unknown, 1 = normal, 2 = hot), read by k_cull, rewritten by k_render.  NULL = no hints.
   uint8_t*  pix_class;             // [local_rows*width]
-  uint32_t  class_t1, class_t2;    // traversal steps: class = (steps >= t1) + (steps >= t2)
+  uint32_t  class_t1, class_t2;    // traversal steps: class = (steps >= t1) + (steps >= t2); t2 == 0: adaptive, see class_hist
+  uint32_t* class_hist;            // [64] histogram of (steps - t1) / 4 over last frame's pixels with steps >= t1 (k_render adds, k_compact reads + clears)
+  uint32_t  class_hot_pct;         // adaptive t2: the hot class is about this share of last frame's non-cheap pixels (k_compact -> list_count[2])
+  uint32_t  render_blocks;         // grid of k_render (number of class_hist rows in use)
   unsigned long long* stats;       // [8]: rays_primary, rays_shadow, rays_bounce, box, tri, hitupd, pixels, drops
   unsigned long long* stats_partial;   // [rt_render_grid()*8] per-block partials of phase B
 };

@@ -606,6 +606,23 @@ __global__ __launch_bounds__(TBLK) void k_compact(const RtRenderParams p) {
   base[1] = tot[2] + tot[N_CLASS + 1];
   base[0] = tot[2] + tot[1] + tot[N_CLASS + 0];
   if (me == 0 && threadIdx.x == 0) { p.list_count[0] = tot[0] + tot[1] + tot[2]; p.list_count[1] = tot[2]; }   // all, hot
+  if (me == 0 && w == TBLK / 64 - 1 && p.pix_class) {   // hot threshold of THIS frame from last frame's step histogram
+    uint32_t t2 = p.class_t2;
+    if (t2 == 0u) {                                       // lane b owns bin b: steps in [t1 + 4 b, t1 + 4 b + 4), last bin open
+      const unsigned long long mine = p.class_hist[lane];
+      p.class_hist[lane] = 0u;                            // this frame's k_render (next launch) accumulates afresh
+      unsigned long long suffix = mine;                   // pixels in bins >= lane
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long t = __shfl_down(suffix, o);
+        if (lane + o < 64) suffix += t;
+      }
+      const unsigned long long total = __shfl(suffix, 0);
+      // first bin whose suffix fits into the hot share; no data -> no hot class
+      const unsigned long long ok = __ballot(total > 0ull && suffix * 100ull <= total * p.class_hot_pct);
+      t2 = ok ? p.class_t1 + 4u * (uint32_t)(__ffsll((long long)ok) - 1) : 0xFFFFFFFFu;
+    }
+    if (lane == 0) p.list_count[2] = max(t2, p.class_t1 + 1u);
+  }
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll 1
   for (int r = 0; r < CULL_TPB / (TBLK / 64); ++r) {
@@ -623,14 +640,13 @@ __global__ __launch_bounds__(TBLK) void k_compact(const RtRenderParams p) {
 }
 
 // Phase B — persistent-thread traversal + shading over the compacted pixel list (all 64 lanes
-// carry rays that enter the tree).  The list's 64-pixel chunks are dealt to N_SHARD queue shards in groups of SHARD_GROUP
+// carry rays that enter the tree).  The list's 64-pixel chunks are dealt to N_SHARD queue shards in groups of p.shard_group
 // consecutive chunks, round-robin, so every shard walks the list front to back (hot -> cheap) and all shards hold the
 // same amount of work; each shard has its own head on its own cache line.  A wave drains its home shard
 // (blocks with equal blockIdx % 8 share an XCD and get neighbouring shards = neighbouring chunk groups,
 // for L2 locality only), then steals from whichever shard a cheap load scan shows non-empty.
-constexpr uint32_t SHARD_GROUP = 8;
-RT_DEV uint32_t shard_chunk(uint32_t shard, uint32_t k) {     // k-th chunk of a shard; increasing in k
-  return ((k / SHARD_GROUP) * N_SHARD + shard) * SHARD_GROUP + (k % SHARD_GROUP);
+RT_DEV uint32_t shard_chunk(uint32_t shard, uint32_t k, uint32_t group) {     // k-th chunk of a shard; increasing in k
+  return ((k / group) * N_SHARD + shard) * group + (k % group);
 }
 #ifdef RT_TIMELINE   // analysis build only (make EXTRA=-DRT_TIMELINE): per-wave start / last-chunk-start / end clocks of k_render
 __device__ unsigned long long g_timeline[4096 * 4][4];
@@ -665,13 +681,17 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
   RayCount R; R.primary = R.shadow = R.bounce = 0;
   uint32_t pixels = 0;
   const uint32_t n_list = *p.list_count;                 // written by k_compact (previous launch on this stream)
+  const uint32_t class_t2 = p.pix_class ? p.list_count[2] : 0xFFFFFFFFu;
+  __shared__ uint32_t s_hist[64];                        // this block's step histogram of non-cheap pixels (next frame's threshold)
+  if (threadIdx.x < 64) s_hist[threadIdx.x] = 0u;
+  __syncthreads();
   const uint32_t n_chunks = (n_list + 63u) / 64u;
   const uint32_t per_xcd = (gridDim.x + 7u) / 8u;
   int shard = (int)((blockIdx.x & 7u) * (N_SHARD / 8) + ((blockIdx.x >> 3) * (N_SHARD / 8)) / per_xcd) & (N_SHARD - 1);
   for (uint32_t scans = 0; scans <= 4u * N_SHARD; ++scans) {          // every wave reaches the exit: a scan that finds nothing
     // lane l looks after shard l
     const uint32_t head = __hip_atomic_load(p.shard_heads + (size_t)lane * p.shard_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned long long avail = __ballot(shard_chunk((uint32_t)lane, head) < n_chunks);
+    unsigned long long avail = __ballot(shard_chunk((uint32_t)lane, head, p.shard_group) < n_chunks);
     if (!avail) break;
     // first non-empty shard at or after `shard` (rotating)
     const unsigned long long rot = (shard == 0) ? avail : ((avail >> shard) | (avail << (64 - shard)));
@@ -679,7 +699,7 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
     for (;;) {
       uint32_t h = 0;
       if (lane == 0) h = atomicAdd(p.shard_heads + (size_t)shard * p.shard_stride, 1u);
-      const uint32_t chunk = shard_chunk((uint32_t)shard, (uint32_t)__builtin_amdgcn_readfirstlane((int)h));
+      const uint32_t chunk = shard_chunk((uint32_t)shard, (uint32_t)__builtin_amdgcn_readfirstlane((int)h), p.shard_group);
       if (chunk >= n_chunks) break;
 #ifdef RT_TIMELINE
       tl_last = wall_clock64(); tl_chunks += 1;
@@ -693,7 +713,10 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
         if (p.rgba8) reinterpret_cast<uint32_t*>(p.rgba8)[idx] = o.rgba;
         if (p.hit_tri) p.hit_tri[idx] = o.tri;
         if (p.hit_t) p.hit_t[idx] = o.t;
-        if (p.pix_class) p.pix_class[idx] = (uint8_t)((o.cost >= p.class_t1 ? 1u : 0u) + (o.cost >= p.class_t2 ? 1u : 0u));
+        if (p.pix_class) {
+          p.pix_class[idx] = (uint8_t)((o.cost >= p.class_t1 ? 1u : 0u) + (o.cost >= class_t2 ? 1u : 0u));
+          if (o.cost >= p.class_t1) atomicAdd(&s_hist[min((o.cost - p.class_t1) >> 2, 63u)], 1u);
+        }
         pixels += 1;
       }
     }
@@ -705,6 +728,10 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
   }
 #endif
   flush_stats<COUNT>(p, lane, R, W, pixels);
+  if (p.pix_class) {                                     // 64 bins, one atomic per non-empty bin and block, spread over the launch's tail
+    __syncthreads();
+    if (threadIdx.x < 64 && s_hist[threadIdx.x]) atomicAdd(&p.class_hist[threadIdx.x], s_hist[threadIdx.x]);
+  }
 }
 
 // surface records into BVH order (the vt / material counterpart of flattenForSSBO's triPos / triNor loop, script.js:530-545)
@@ -807,9 +834,11 @@ void rt_cull_rect(RtRenderParams& p, const float rb[8]) {
   p.cull_y0 = (int)std::fmax(0.0, std::fmin(y0, H));  p.cull_y1 = (int)std::fmin(H - 1.0, std::fmax(y1, -1.0));
 }
 
-void rt_launch_render(const RtRenderParams& p, int layout, bool count_work, bool want_stats, int n_cu, hipStream_t s, hipEvent_t ev0,
+void rt_launch_render(const RtRenderParams& p_in, int layout, bool count_work, bool want_stats, int n_cu, hipStream_t s, hipEvent_t ev0,
                       hipEvent_t ev1) {
+  RtRenderParams p = p_in;
   const dim3 b(TBLK), gc(rt_cull_blocks(p.n_tiles));
+  p.render_blocks = resident_grid(n_cu, p.max_stack, p.tri_uv != nullptr);
   hipLaunchKernelGGL(k_cull, gc, b, 0, s, p);
   hipLaunchKernelGGL(k_compact, gc, b, 0, s, p);
   const dim3 g(resident_grid(n_cu, p.max_stack, p.tri_uv != nullptr));
