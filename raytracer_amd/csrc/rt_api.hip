@@ -339,6 +339,7 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
   if (errw & 8u) {   // the write-through hand-off was caught stale by k_refit_verify: redo with full fences
     ctx->refit_fallbacks += 1;
     HIPCHK(hipMemsetAsync(ctx->words.p + 2, 0, sizeof(uint32_t), s));
+    if (T > 1) HIPCHK(hipMemsetAsync(ctx->visit.p, 0, sizeof(uint32_t) * (size_t)(T - 1), s));   // arrival counters (k_karras zeroed them once)
     rt_launch_refit(b, ctx->own_nodes.p, ctx->own_tri_pos.p, ctx->own_tri_nor.p, ctx->wide.p, ctx->tri_pre.p, leaf_shift, /*fenced=*/true, v2, s);
     HIPCHK(hipEventRecord(ctx->ev[5], s));
     HIPCHK(hipMemcpyAsync(&errw, ctx->words.p + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));

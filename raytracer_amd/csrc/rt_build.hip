@@ -83,8 +83,12 @@ __global__ __launch_bounds__(BLK) void k_bounds(const float* __restrict__ pos, c
 
 // fold the block partials (6 waves, one per component), then the `Bounds` uniform of morton_compute.wgsl:3-6:
 // invExtent = 1/(max-min), 0 where the extent is 0
-__global__ __launch_bounds__(384) void k_bounds_final(const uint32_t* __restrict__ part, uint32_t n_blocks, float* bounds_f) {
+__global__ __launch_bounds__(384) void k_bounds_final(const uint32_t* __restrict__ part, uint32_t n_blocks, float* bounds_f,
+                                                      uint32_t* __restrict__ hist, uint32_t* __restrict__ tile_counter) {
   __shared__ uint32_t s[6];
+  // the sort's global digit histograms and tile tickets start at zero (saves three memset launches)
+  for (int i = threadIdx.x; i < 4 * RADIX; i += 384) hist[i] = 0u;
+  if (threadIdx.x < 4) tile_counter[threadIdx.x] = 0u;
   const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
   uint32_t v = (k < 3) ? 0xFFFFFFFFu : 0u;
   for (uint32_t b = lane; b < n_blocks; b += 64) {
@@ -107,7 +111,9 @@ __global__ __launch_bounds__(384) void k_bounds_final(const uint32_t* __restrict
 __global__ __launch_bounds__(BLK) void k_morton(const float* __restrict__ centroids,
                                                 uint32_t n_tri, const float* __restrict__ bounds_f,
                                                 uint32_t* __restrict__ codes, uint32_t* __restrict__ keys,
-                                                uint32_t* __restrict__ vals) {
+                                                uint32_t* __restrict__ vals, uint32_t* __restrict__ tile_status, size_t n_status) {
+  // the look-back words of the four sort passes start at zero (their own memset launch otherwise)
+  for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < n_status; i += (size_t)gridDim.x * BLK) tile_status[i] = 0u;
   const V3 bmin = v3(bounds_f[0], bounds_f[1], bounds_f[2]), inv = v3(bounds_f[4], bounds_f[5], bounds_f[6]);
   for (uint32_t t = blockIdx.x * BLK + threadIdx.x; t < n_tri; t += gridDim.x * BLK) {
     const V3 ctr = v3(centroids[3 * (size_t)t + 0], centroids[3 * (size_t)t + 1], centroids[3 * (size_t)t + 2]);   // :52, from k_bounds
@@ -283,11 +289,13 @@ RT_DEV int kdelta(const uint32_t* __restrict__ k, int n, int i, uint32_t ki, int
 }
 
 __global__ __launch_bounds__(BLK) void k_karras(const uint32_t* __restrict__ k, uint32_t n_tri,
-                                                int32_t* __restrict__ child, int32_t* __restrict__ parent) {
+                                                int32_t* __restrict__ child, int32_t* __restrict__ parent,
+                                                uint32_t* __restrict__ visit) {
   const int n = (int)n_tri;
   const int i = blockIdx.x * BLK + threadIdx.x;
   if (i == 0) parent[0] = -1;
   if (i >= n - 1) return;
+  visit[i] = 0u;                                   // the refit's arrival counter of this node (its own memset launch otherwise)
   const uint32_t ki = k[i];
   const int d = (kdelta(k, n, i, ki, i + 1) - kdelta(k, n, i, ki, i - 1)) > 0 ? 1 : -1;
   const int dmin = kdelta(k, n, i, ki, i - d);
@@ -537,19 +545,17 @@ uint32_t rt_bounds_words() { return 6u * 2048u; }   // grid_for's block cap x 6 
 void rt_launch_bounds(const RtBuildBuffers& b, hipStream_t s) {
   const int g = grid_for(b.n_tri, BLK);
   hipLaunchKernelGGL(k_bounds, dim3(g), dim3(BLK), 0, s, b.pos, b.vidx, b.n_tri, b.bounds_enc, b.centroids);
-  hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(384), 0, s, b.bounds_enc, (uint32_t)g, b.bounds_f);
+  hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(384), 0, s, b.bounds_enc, (uint32_t)g, b.bounds_f, b.hist, b.tile_counter);
 }
 
 void rt_launch_morton(const RtBuildBuffers& b, hipStream_t s) {
   hipLaunchKernelGGL(k_morton, dim3(grid_for(b.n_tri, BLK)), dim3(BLK), 0, s, b.centroids, b.n_tri, b.bounds_f, b.codes,
-                     b.keys_a, b.vals_a);
+                     b.keys_a, b.vals_a, b.tile_status, rt_sort_status_words(b.n_tri));
 }
 
 void rt_launch_sort(const RtBuildBuffers& b, hipStream_t s) {
   const uint32_t n = b.n_tri, tiles = rt_sort_tile_count(n);
-  (void)hipMemsetAsync(b.hist, 0, sizeof(uint32_t) * 4 * RADIX, s);
-  (void)hipMemsetAsync(b.tile_status, 0, sizeof(uint32_t) * rt_sort_status_words(n), s);
-  (void)hipMemsetAsync(b.tile_counter, 0, sizeof(uint32_t) * 4, s);
+  // hist / tile_counter were zeroed by k_bounds_final, tile_status by k_morton
   hipLaunchKernelGGL(k_sort_hist, dim3(grid_for(n, BLK * 8)), dim3(BLK), 0, s, b.keys_a, n, b.hist);
   hipLaunchKernelGGL(k_sort_scan, dim3(4), dim3(BLK), 0, s, b.hist);
   uint32_t *ki = b.keys_a, *vi = b.vals_a, *ko = b.keys_b, *vo = b.vals_b;
@@ -564,12 +570,11 @@ void rt_launch_sort(const RtBuildBuffers& b, hipStream_t s) {
 
 void rt_launch_karras(const RtBuildBuffers& b, hipStream_t s) {
   const uint32_t n_int = b.n_tri > 1 ? b.n_tri - 1 : 1;
-  hipLaunchKernelGGL(k_karras, dim3((n_int + BLK - 1) / BLK), dim3(BLK), 0, s, b.keys_a, b.n_tri, b.child, b.parent);
+  hipLaunchKernelGGL(k_karras, dim3((n_int + BLK - 1) / BLK), dim3(BLK), 0, s, b.keys_a, b.n_tri, b.child, b.parent, b.visit);
 }
 
 void rt_launch_refit(const RtBuildBuffers& b, float* nodes, float* tri_pos, float* tri_nor, float4* wide, float4* tri_pre,
                      int leaf_shift, bool fenced, bool v2, hipStream_t s) {
-  if (b.n_tri > 1) (void)hipMemsetAsync(b.visit, 0, sizeof(uint32_t) * (b.n_tri - 1), s);
   const dim3 g((b.n_tri + BLK - 1) / BLK), blk(BLK);
   if (fenced)
     hipLaunchKernelGGL(k_refit<true>, g, blk, 0, s, b.pos, b.nor, b.vidx, b.nidx, b.vals_a, b.n_tri, b.child, b.parent, b.visit,
