@@ -79,6 +79,8 @@ struct rt_ctx {
 
   // render scratch, one set per frame slot (slot 0 = the context stream; slots 0/1 alternate with two frames in flight)
   DevBuf<uint32_t> r_tile_counter[2], r_list[2];
+  DevBuf<float4> pt_recs[2];                   // PT split records (rt_trace.hip), per frame slot
+  DevBuf<float> pt_terms[2];
   DevBuf<unsigned long long> r_stats[2];
   // frames in flight (rt_set_frames_in_flight): asynchronous frames alternate between two frame streams so that the
   // tail of frame i (few waves left, latency-bound) overlaps the head of frame i+1
@@ -225,7 +227,7 @@ extern "C" void rt_destroy(rt_ctx* ctx) {
   for (auto& t : ctx->texels) t.release();
   ctx->tex_table.release();
   for (int k = 0; k < 2; ++k) {
-    ctx->r_tile_counter[k].release(); ctx->r_list[k].release(); ctx->r_stats[k].release();
+    ctx->r_tile_counter[k].release(); ctx->r_list[k].release(); ctx->r_stats[k].release(); ctx->pt_recs[k].release(); ctx->pt_terms[k].release();
     if (ctx->fstream[k]) { (void)hipStreamSynchronize(ctx->fstream[k]); (void)hipStreamDestroy(ctx->fstream[k]); }
     if (ctx->f_done[k]) (void)hipEventDestroy(ctx->f_done[k]);
   }
@@ -771,14 +773,33 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
   } else {
     JOIN_FRAMES();
   }
-  HIPCHK(ctx->r_tile_counter[slot].ensure(rt_shard_words() + 32 + 3 * (size_t)cull_blocks));
+  HIPCHK(ctx->r_tile_counter[slot].ensure(2 * (size_t)rt_shard_words() + 32 + 64 + 3 * (size_t)cull_blocks));
   HIPCHK(ctx->r_stats[slot].ensure(8 + 32 + (size_t)rt_render_grid(ctx->n_cu) * 8 + 3 * (size_t)p.n_tiles));
   HIPCHK(ctx->r_list[slot].ensure((size_t)p.local_rows * p.width));
   p.shard_stride = rt_shard_stride();
   p.shard_group = 8;
+  // PT split (sample-parallel GI) wherever its fixed-size term registers suffice; RTCORE_PT_SPLIT=0 keeps one lane per pixel
+  {
+    bool split = opts->mode == RT_MODE_PT && opts->gi_samples >= 2 && opts->gi_bounces >= 1 && opts->gi_bounces <= 4;
+    if (const char* e = std::getenv("RTCORE_PT_SPLIT")) split = split && std::atoi(e) != 0;
+    p.pt_cap = 0;
+    if (split && p.n_tiles > 0) p.pt_cap = 1;   // sized below, once shard_group is final
+  }
   if (const char* e = std::getenv("RTCORE_SHARD_GROUP")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) p.shard_group = (uint32_t)v; }
+  if (p.pt_cap) {
+    p.pt_cap = rt_pt_capacity(p.local_rows * p.width, p.shard_group);
+    const size_t n_terms = (size_t)64 * p.pt_cap * (size_t)opts->gi_samples * ((size_t)opts->gi_bounces * 3 + 1);
+    if (n_terms * sizeof(float) > ((size_t)12 << 30)) p.pt_cap = 0;    // the bounce terms would not fit a modest budget: one lane per pixel
+    else {
+      HIPCHK(ctx->pt_recs[slot].ensure((size_t)64 * p.pt_cap * 3));
+      HIPCHK(ctx->pt_terms[slot].ensure(n_terms));
+      p.pt_recs = ctx->pt_recs[slot].p; p.pt_terms = ctx->pt_terms[slot].p;
+    }
+  }
   p.shard_heads = ctx->r_tile_counter[slot].p; p.list_count = ctx->r_tile_counter[slot].p + rt_shard_words();
-  p.block_total = ctx->r_tile_counter[slot].p + rt_shard_words() + 32;
+  p.pt_heads = ctx->r_tile_counter[slot].p + rt_shard_words() + 32;
+  p.pt_count = p.pt_heads + rt_shard_words();
+  p.block_total = p.pt_count + 64;
   p.list = ctx->r_list[slot].p;
   p.stats = ctx->r_stats[slot].p; p.stats_partial = ctx->r_stats[slot].p + 8 + 32;
   p.class_hist = reinterpret_cast<uint32_t*>(ctx->r_stats[slot].p + 8);   // 64 u32
@@ -807,7 +828,7 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
     // 48: 0.41, 64: 0.43; cfg 5 best at 80), so the hot threshold follows last frame's step histogram instead.
     // PT pixels are a chain of ~50 traversals whatever their class: only hit / miss is separated there.
     p.class_t1 = 16u;
-    p.class_t2 = (opts->mode == RT_MODE_PT) ? 0xFFFFFFFFu : 0u;   // 0 = adaptive: the top class_hot_pct % of last frame's non-cheap pixels
+    p.class_t2 = (opts->mode == RT_MODE_PT && !p.pt_cap) ? 0xFFFFFFFFu : 0u;   // 0 = adaptive: the top class_hot_pct % of last frame's non-cheap pixels
     p.class_hot_pct = 20u;    // measured: 20 / 30 / 40 / 50 % -> k_render 0.394 / 0.415 / 0.394 / 0.451 ms (cfg 3), 3.20 / 3.21 / 3.23 / 3.27 ms (cfg 5)
     if (const char* e = std::getenv("RTCORE_HOT_PCT")) p.class_hot_pct = (uint32_t)std::atoll(e);
     if (const char* e = std::getenv("RTCORE_T1")) p.class_t1 = (uint32_t)std::atoll(e);

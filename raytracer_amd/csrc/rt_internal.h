@@ -77,6 +77,13 @@ struct RtRenderParams {
   uint32_t  class_t1, class_t2;    // traversal steps: class = (steps >= t1) + (steps >= t2); t2 == 0: adaptive, see class_hist
   uint32_t* class_hist;            // [64] histogram of (steps - t1) / 4 over last frame's pixels with steps >= t1 (k_render adds, k_compact reads + clears)
   uint32_t  class_hot_pct;         // adaptive t2: the hot class is about this share of last frame's non-cheap pixels (k_compact -> list_count[2])
+  // PT split (sample-parallel GI, rt_trace.hip): phase 1 (k_render) leaves one record per hit pixel in the sub-list of the queue
+  // shard its chunk came from; phase 2 (k_pt_samples) traces ONE GI sample of 64 records per wave item, phase 3 (k_pt_resolve) sums.  pt_cap == 0: no split.
+  float4*   pt_recs;               // [N_SHARD][pt_cap][3]: {hit_pos, d0} {n_os, bits(pixel idx)} {albedo, bits(pixelIndex)}
+  uint32_t* pt_count;              // [N_SHARD] records per sub-list           (zeroed by k_cull)
+  uint32_t* pt_heads;              // [N_SHARD * shard_stride] phase-2 queue heads (zeroed by k_cull)
+  uint32_t  pt_cap;
+  float*    pt_terms;              // [gi_samples][gi_bounces * 3 + 1][N_SHARD * pt_cap]: bounce terms + their count per (sample, record)
   uint32_t  render_blocks;         // grid of k_render (number of class_hist rows in use)
   unsigned long long* stats;       // [8]: rays_primary, rays_shadow, rays_bounce, box, tri, hitupd, pixels, drops
   unsigned long long* stats_partial;   // [rt_render_grid()*8] per-block partials of phase B
@@ -120,6 +127,7 @@ void rt_launch_pack_impl(const RtBvhDev& bvh, uint32_t* d_root_ref, uint32_t* d_
 uint32_t rt_render_grid(int n_cu);   // blocks of the persistent phase-B grid
 uint32_t rt_cull_blocks(uint32_t n_tiles);
 uint32_t rt_shard_words();
+uint32_t rt_pt_capacity(uint32_t n_pixels, uint32_t shard_group);   // records per PT sub-list that can never overflow
 uint32_t rt_shard_stride();
 // ev0/ev1 (optional) are recorded immediately before/after the traversal kernel proper
 // want_stats == false skips the k_stats_final reduction (p.stats is then not written)

@@ -439,6 +439,63 @@ RT_DEV PixelOut shade_pixel(const Scene& S, const Shade& sh, const float* U, uin
   return out;
 }
 
+// ---- PT split: the pixel's work of compute.wgsl:349-410 in two parts with identical arithmetic -----------------------
+// A PT pixel is one chain of GI_SAMPLES x GI_BOUNCES dependent traversals (cfg 4: 48 closest-hit + up to 240 shadow walks,
+// ~4 ms) while the whole frame is ~2.5 ms of work: with one lane per pixel the launch was 5.2 ms, half of it a tail of
+// few waves.  The GI samples of a pixel are independent chains; only their SUM has an order (`indirect +=` runs over i,
+// then b, compute.wgsl:376-404).  Part 1 = everything outside the GI loop; part 2 = one lane per (pixel, sample), then the
+// terms are added in exactly that order by part 3.
+struct PtRec { V3 hit_pos, n_os, albedo; float d0; uint32_t idx, pixelIndex; };
+
+template <int LAYOUT, bool COUNT, bool TEX>
+RT_DEV PixelOut shade_pt_primary(const Scene& S, const Shade& sh, const float* U, uint32_t gx, uint32_t gy, uint32_t w, uint32_t h,
+                                 float time_h, Work& W, RayCount& R, PtRec& rec, bool& is_hit) {
+  const PrimaryRay pr = primary_ray(U, gx, gy, w, h);
+  PixelOut out;
+  R.primary += 1;
+  const Hit hit0 = closest<LAYOUT, COUNT>(S, pr.ro, pr.rd, pr.inv, 1e20f, W);
+  out.tri = hit0.tri; out.t = hit0.t; out.cost = hit0.steps; out.rgba = 0xFF000000u;
+  is_hit = !(hit0.t >= 1e19f);
+  if (!is_hit) { out.tri = 0xFFFFFFFFu; return out; }                    // (0,0,0,1), compute.wgsl:365-367
+  rec.hit_pos = fma3(pr.rd, hit0.t, pr.ro);
+  rec.n_os = hit_normal(S, hit0);
+  rec.albedo = TEX ? hit_albedo(S, hit0) : v3(1.0f, 0.84f, 0.0f);
+  rec.pixelIndex = pr.pixelIndex;
+  rec.d0 = direct_radiance<LAYOUT, COUNT>(S, sh, rec.hit_pos, rec.n_os, pr.light, pr.pixelIndex, time_h, W, R);   // :408
+  return out;
+}
+
+// One GI sample i of a pixel: compute.wgsl:378-403.  term[b] = throughput * dS of bounce b, n_terms of them.
+template <int LAYOUT, bool COUNT, bool TEX>
+RT_DEV void pt_sample_chain(const Scene& S, const Shade& sh, const float* U, const PtRec& rec, V3 light_os, uint32_t i, float time_h,
+                            Work& W, RayCount& R, V3 term[4], uint32_t& n_terms) {
+  const uint32_t NB = (uint32_t)sh.gi_bounces;
+  const float pixelSeed = (float)rec.pixelIndex / (U[36] * U[37]);
+  V3 throughput = rec.albedo;
+  V3 ro_b = fma3(rec.n_os, 0.001f, rec.hit_pos);
+  V3 n_b = rec.n_os;
+  n_terms = 0;
+#pragma unroll
+  for (uint32_t b = 0; b < 4; ++b) {
+    if (b >= NB) break;
+    const float bounceSeed = (float)b * 101.0f + (float)i;
+    const float s1 = rand2(bounceSeed, __fmaf_rn(pixelSeed, (float)i, 17.0f) + time_h);
+    const float s2 = rand2(__fmaf_rn(pixelSeed, (float)i, 37.0f) + time_h, bounceSeed);
+    const V3 dir = sample_hemisphere(n_b, s1, s2);
+    R.bounce += 1;
+    const Hit hb = closest<LAYOUT, COUNT>(S, ro_b, dir, rcp3(dir), 1e20f, W);
+    if (hb.t >= 1e19f) break;
+    const V3 pB = fma3(dir, hb.t, ro_b);
+    const V3 nB = hit_normal(S, hb);
+    const float dS = direct_radiance<LAYOUT, COUNT>(S, sh, pB, nB, light_os, rec.pixelIndex, time_h, W, R);
+    term[b] = throughput * dS;
+    n_terms = b + 1u;
+    throughput = throughput * (TEX ? hit_albedo(S, hb) : rec.albedo);      // :400
+    ro_b = fma3(nB, 0.0001f, pB);
+    n_b = nB;
+  }
+}
+
 RT_DEV uint32_t wave_sum_u32(uint32_t v) {
   for (int o = 32; o >= 1; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
   return v;
@@ -514,7 +571,10 @@ __global__ __launch_bounds__(TBLK) void k_cull(const RtRenderParams p) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float4 ra = reinterpret_cast<const float4*>(p.nodes)[0], rb = reinterpret_cast<const float4*>(p.nodes)[1];
   if (blockIdx.x == 0)   // phase-B queue heads start at zero (k_render runs two launches later)
-    for (uint32_t i = threadIdx.x; i < (uint32_t)(N_SHARD * SHARD_STRIDE); i += TBLK) p.shard_heads[i] = 0u;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(N_SHARD * SHARD_STRIDE); i += TBLK) {
+      p.shard_heads[i] = 0u;
+      if (p.pt_cap) { p.pt_heads[i] = 0u; if (i < (uint32_t)N_SHARD) p.pt_count[i] = 0u; }
+    }
 #pragma unroll 1
   for (int r = 0; r < CULL_TPB / (TBLK / 64); ++r) {
     const int k = r * (TBLK / 64) + w;                       // the 4 waves of a block work on 4 adjacent tiles
@@ -655,7 +715,7 @@ extern "C" int rt_debug_timeline(unsigned long long* out, size_t n_words) {
 }
 #endif
 
-template <int LAYOUT, bool COUNT, bool TEX>
+template <int LAYOUT, bool COUNT, bool TEX, bool PTSPLIT>
 __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
 #ifdef RT_TIMELINE
@@ -705,12 +765,16 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
       tl_last = wall_clock64(); tl_chunks += 1;
 #endif
       const uint32_t li = chunk * 64u + (uint32_t)lane;
+      PtRec rec;
+      bool rec_hit = false;
       if (li < n_list) {
         const uint32_t idx = p.list[li];
         const uint32_t x = idx % p.width, lrow = idx / p.width;
         const uint32_t y = local_to_global_row(p, lrow);
-        const PixelOut o = shade_pixel<LAYOUT, COUNT, TEX>(S, sh, p.U, x, y, p.width, p.height, time_h, W, R);
-        if (p.rgba8) reinterpret_cast<uint32_t*>(p.rgba8)[idx] = o.rgba;
+        PixelOut o;
+        if constexpr (PTSPLIT) { o = shade_pt_primary<LAYOUT, COUNT, TEX>(S, sh, p.U, x, y, p.width, p.height, time_h, W, R, rec, rec_hit); rec.idx = idx; }
+        else o = shade_pixel<LAYOUT, COUNT, TEX>(S, sh, p.U, x, y, p.width, p.height, time_h, W, R);
+        if (p.rgba8 && !rec_hit) reinterpret_cast<uint32_t*>(p.rgba8)[idx] = o.rgba;     // a PT hit pixel gets its colour in part 2
         if (p.hit_tri) p.hit_tri[idx] = o.tri;
         if (p.hit_t) p.hit_t[idx] = o.t;
         if (p.pix_class) {
@@ -718,6 +782,21 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
           if (o.cost >= p.class_t1) atomicAdd(&s_hist[min((o.cost - p.class_t1) >> 2, 63u)], 1u);
         }
         pixels += 1;
+      }
+      if constexpr (PTSPLIT) {                              // append the chunk's hit records to the sub-list of its shard: one atomic per chunk
+        const unsigned long long hm = __ballot(rec_hit);
+        if (hm) {
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(p.pt_count + shard, (uint32_t)__popcll(hm));
+          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+          if (rec_hit) {
+            const uint32_t r = base + (uint32_t)__popcll(hm & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+            float4* d = p.pt_recs + ((size_t)shard * p.pt_cap + r) * 3;
+            d[0] = make_float4(rec.hit_pos.x, rec.hit_pos.y, rec.hit_pos.z, rec.d0);
+            d[1] = make_float4(rec.n_os.x, rec.n_os.y, rec.n_os.z, __uint_as_float(rec.idx));
+            d[2] = make_float4(rec.albedo.x, rec.albedo.y, rec.albedo.z, __uint_as_float(rec.pixelIndex));
+          }
+        }
       }
     }
   }
@@ -732,6 +811,97 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
     __syncthreads();
     if (threadIdx.x < 64 && s_hist[threadIdx.x]) atomicAdd(&p.class_hist[threadIdx.x], s_hist[threadIdx.x]);
   }
+}
+
+// PT part 2 — persistent.  A wave item = (64 records of one sub-list, ONE GI sample i): lane = pixel, as in k_render, so the
+// 64 rays of a wave-step keep the coherence of neighbouring pixels that share the sample's random numbers (F7 / §8a-17) —
+// giving the 64 lanes to 16 samples of 4 pixels instead was 25 % SLOWER than no split at all (incoherent gathers).
+// The bounce terms throughput * dS go to HBM (SoA, coalesced); part 3 adds them in the reference's order.
+template <int LAYOUT, bool COUNT, bool TEX>
+__global__ __launch_bounds__(TBLK) void k_pt_samples(const RtRenderParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  uint32_t* stk_ref = reinterpret_cast<uint32_t*>(smem);
+  float* stk_t = reinterpret_cast<float*>(smem + sizeof(uint32_t) * (size_t)p.max_stack * TBLK);
+  Scene S;
+  S.nodes = reinterpret_cast<const float4*>(p.nodes);
+  S.tri_pos = reinterpret_cast<const float4*>(p.tri_pos);
+  S.tri_nor = reinterpret_cast<const float4*>(p.tri_nor);
+  S.wide = p.wide; S.tri_pre = p.tri_pre;
+  S.root_ref = p.root_ref; S.leaf_shift = p.leaf_shift; S.v2 = p.nodes_v2 != 0; S.max_stack = p.max_stack; S.step_budget = p.step_budget;
+  S.stk_ref = stk_ref + threadIdx.x; S.stk_t = stk_t + threadIdx.x;
+  S.tri_uv = p.tri_uv; S.materials = p.materials; S.textures = p.textures; S.n_materials = p.n_materials; S.n_textures = p.n_textures;
+  Shade sh; sh.mode = p.mode; sh.gi_samples = p.gi_samples; sh.gi_bounces = p.gi_bounces; sh.soft_samples = p.soft_samples;
+
+  const int lane = threadIdx.x & 63;
+  const float time_h = (float)hash_u32(sat_u32(p.U[38]));          // compute.wgsl:444
+  const V3 light_os = mat_mul4(p.U + 20, p.U[4], p.U[5], p.U[6], p.U[7]);   // :360, as primary_ray
+  Work W; W.box = W.tri = W.hit = W.drops = 0;
+  RayCount R; R.primary = R.shadow = R.bounce = 0;
+  const uint32_t GI = (uint32_t)p.gi_samples, NB = (uint32_t)p.gi_bounces;
+  const size_t cap_total = (size_t)N_SHARD * p.pt_cap;
+
+  // lane s looks after sub-list s: ceil(count / 64) record chunks x GI samples, chunk-major
+  const uint32_t my_cnt = p.pt_count[lane], my_items = ((my_cnt + 63u) / 64u) * GI;
+  const uint32_t per_xcd = (gridDim.x + 7u) / 8u;
+  int shard = (int)((blockIdx.x & 7u) * (N_SHARD / 8) + ((blockIdx.x >> 3) * (N_SHARD / 8)) / per_xcd) & (N_SHARD - 1);
+  for (uint32_t scans = 0; scans <= 4u * N_SHARD; ++scans) {          // every wave reaches the exit: a scan that finds nothing
+    const uint32_t head = __hip_atomic_load(p.pt_heads + (size_t)lane * p.shard_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long avail = __ballot(head < my_items);
+    if (!avail) break;
+    const unsigned long long rot = (shard == 0) ? avail : ((avail >> shard) | (avail << (64 - shard)));
+    shard = (shard + (__ffsll((long long)rot) - 1)) & (N_SHARD - 1);
+    const uint32_t n_items = (uint32_t)__shfl((int)my_items, shard), cnt = (uint32_t)__shfl((int)my_cnt, shard);
+    for (;;) {
+      uint32_t h = 0;
+      if (lane == 0) h = atomicAdd(p.pt_heads + (size_t)shard * p.shard_stride, 1u);
+      const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
+      if (item >= n_items) break;
+      const uint32_t r = (item / GI) * 64u + (uint32_t)lane, i = item % GI;
+      if (r < cnt) {
+        const size_t g = (size_t)shard * p.pt_cap + r;
+        const float4* d = p.pt_recs + g * 3;
+        const float4 a = d[0], b4 = d[1], c = d[2];
+        PtRec rec;
+        rec.hit_pos = xyz(a); rec.d0 = a.w; rec.n_os = xyz(b4); rec.idx = __float_as_uint(b4.w);
+        rec.albedo = xyz(c); rec.pixelIndex = __float_as_uint(c.w);
+        V3 term[4];
+        term[0] = term[1] = term[2] = term[3] = v3(0.0f, 0.0f, 0.0f);
+        uint32_t n_terms = 0;
+        pt_sample_chain<LAYOUT, COUNT, TEX>(S, sh, p.U, rec, light_os, i, time_h, W, R, term, n_terms);
+        float* t = p.pt_terms + (size_t)i * (NB * 3u + 1u) * cap_total + g;     // [i][b][xyz | n][record]
+#pragma unroll
+        for (uint32_t b = 0; b < 4; ++b)
+          if (b < n_terms) { t[(b * 3u + 0u) * cap_total] = term[b].x; t[(b * 3u + 1u) * cap_total] = term[b].y; t[(b * 3u + 2u) * cap_total] = term[b].z; }
+        t[(size_t)NB * 3u * cap_total] = __uint_as_float(n_terms);
+      }
+    }
+  }
+  flush_stats<COUNT>(p, lane, R, W, 0u);
+}
+
+// PT part 3 — `indirect +=` in the order of compute.wgsl:376-404 (samples ascending, bounces ascending), then :405-409.
+__global__ __launch_bounds__(TBLK) void k_pt_resolve(const RtRenderParams p) {
+  const uint32_t shard = blockIdx.y, r = blockIdx.x * TBLK + threadIdx.x;
+  if (r >= p.pt_count[shard]) return;
+  const uint32_t GI = (uint32_t)p.gi_samples, NB = (uint32_t)p.gi_bounces;
+  const size_t cap_total = (size_t)N_SHARD * p.pt_cap, g = (size_t)shard * p.pt_cap + r;
+  const float4* d = p.pt_recs + g * 3;
+  const float4 a = d[0], b4 = d[1], c = d[2];
+  V3 indirect = v3(0.0f, 0.0f, 0.0f);
+  for (uint32_t i = 0; i < GI; ++i) {
+    const float* t = p.pt_terms + (size_t)i * (NB * 3u + 1u) * cap_total + g;
+    const uint32_t n = __float_as_uint(t[(size_t)NB * 3u * cap_total]);
+    for (uint32_t b = 0; b < n; ++b)
+      indirect = indirect + v3(t[(b * 3u + 0u) * cap_total], t[(b * 3u + 1u) * cap_total], t[(b * 3u + 2u) * cap_total]);
+  }
+  indirect = indirect / (float)GI;
+  const V3 albedo = xyz(c);
+  const float d0 = a.w;
+  const V3 col = v3(__fmaf_rn(albedo.x, d0, indirect.x), __fmaf_rn(albedo.y, d0, indirect.y), __fmaf_rn(albedo.z, d0, indirect.z));
+  const float gm = 1.0f / 2.2f;
+  if (p.rgba8)
+    reinterpret_cast<uint32_t*>(p.rgba8)[__float_as_uint(b4.w)] =
+        unorm8(rt_pow(col.x, gm)) | (unorm8(rt_pow(col.y, gm)) << 8) | (unorm8(rt_pow(col.z, gm)) << 16) | 0xFF000000u;
 }
 
 // surface records into BVH order (the vt / material counterpart of flattenForSSBO's triPos / triNor loop, script.js:530-545)
@@ -766,15 +936,15 @@ __global__ __launch_bounds__(TBLK) void k_deinterleave(const T* __restrict__ pac
 // Persistent grid of phase B: what is actually resident (occupancy query), so that no block starts
 // late behind another one (measured: with a 4-blocks/CU grid and 3 resident, a quarter of the
 // waves started 400 us into a 650 us launch).
-uint32_t rt_render_grid(int n_cu) { return (uint32_t)n_cu * 4u; }   // upper bound (sizes the per-block stats slots)
+uint32_t rt_render_grid(int n_cu) { return (uint32_t)n_cu * 8u; }   // upper bound (sizes the per-block stats slots: two launches with the PT split)
 static uint32_t resident_grid(int n_cu, int max_stack, bool tex) {
   static int per_cu[2][33] = {};
   int& slot = per_cu[tex ? 1 : 0][max_stack];
   if (slot == 0) {
     int nb = 0;
     const size_t lds = (size_t)max_stack * TBLK * 8;
-    const hipError_t e = tex ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_render<RT_LAYOUT_WIDE64, true, true>), TBLK, lds)
-                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_render<RT_LAYOUT_WIDE64, true, false>), TBLK, lds);
+    const hipError_t e = tex ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_render<RT_LAYOUT_WIDE64, true, true, false>), TBLK, lds)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_render<RT_LAYOUT_WIDE64, true, false, false>), TBLK, lds);
     if (e != hipSuccess || nb < 1) nb = 2;
     slot = nb > 4 ? 4 : nb;
     if (const char* e = getenv("RTCORE_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= slot) slot = v; }
@@ -784,6 +954,11 @@ static uint32_t resident_grid(int n_cu, int max_stack, bool tex) {
 uint32_t rt_cull_blocks(uint32_t n_tiles) { return (n_tiles + CULL_TPB - 1) / CULL_TPB; }
 uint32_t rt_shard_words() { return N_SHARD * (uint32_t)shard_stride_words(); }
 uint32_t rt_shard_stride() { return (uint32_t)shard_stride_words(); }
+// a shard owns at most ceil(n_chunks / (N_SHARD * group)) groups of `group` chunks of 64 pixels
+uint32_t rt_pt_capacity(uint32_t n_pixels, uint32_t group) {
+  const uint64_t chunks = ((uint64_t)n_pixels + 63u) / 64u, per = (uint64_t)N_SHARD * group;
+  return (uint32_t)(((chunks + per - 1u) / per) * group * 64u);
+}
 
 // k_cull zeroes shard_heads; masks / block_total / list / list_count / stats are fully rewritten.
 // Screen-space rectangle of the root box.  A primary ray through pixel-plane point s = (sx, sy, 1) has
@@ -844,8 +1019,18 @@ void rt_launch_render(const RtRenderParams& p_in, int layout, bool count_work, b
   const dim3 g(resident_grid(n_cu, p.max_stack, p.tri_uv != nullptr));
   const size_t lds = (size_t)p.max_stack * TBLK * (sizeof(uint32_t) + sizeof(float));
   if (ev0) (void)hipEventRecord(ev0, s);
-  const bool tex = p.tri_uv != nullptr;
-#define RT_LAUNCH_RENDER(L, C, X) hipLaunchKernelGGL((k_render<L, C, X>), g, b, lds, s, p)
+  const bool tex = p.tri_uv != nullptr, split = p.pt_cap != 0;
+  // PT split: part 1 (k_render<..., true>) then part 2 (k_pt_samples) with its own rows of the per-block stats partials
+  RtRenderParams p2 = p;
+  p2.stats_partial = p.stats_partial + (size_t)g.x * 8;
+#define RT_LAUNCH_RENDER(L, C, X)                                                              \
+  do {                                                                                          \
+    if (split) {                                                                                \
+      hipLaunchKernelGGL((k_render<L, C, X, true>), g, b, lds, s, p);                           \
+      hipLaunchKernelGGL((k_pt_samples<L, C, X>), g, b, lds, s, p2);                            \
+      hipLaunchKernelGGL(k_pt_resolve, dim3((p.pt_cap + TBLK - 1) / TBLK, N_SHARD), b, 0, s, p); \
+    } else hipLaunchKernelGGL((k_render<L, C, X, false>), g, b, lds, s, p);                     \
+  } while (0)
   if (layout == RT_LAYOUT_WIDE64) {
     if (count_work) { if (tex) RT_LAUNCH_RENDER(RT_LAYOUT_WIDE64, true, true); else RT_LAUNCH_RENDER(RT_LAYOUT_WIDE64, true, false); }
     else { if (tex) RT_LAUNCH_RENDER(RT_LAYOUT_WIDE64, false, true); else RT_LAUNCH_RENDER(RT_LAYOUT_WIDE64, false, false); }
@@ -855,7 +1040,7 @@ void rt_launch_render(const RtRenderParams& p_in, int layout, bool count_work, b
   }
 #undef RT_LAUNCH_RENDER
   if (ev1) (void)hipEventRecord(ev1, s);
-  if (want_stats) hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(256), 0, s, p, g.x, p.local_rows * p.width, count_work ? 1 : 0);
+  if (want_stats) hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(256), 0, s, p, split ? 2u * g.x : g.x, p.local_rows * p.width, count_work ? 1 : 0);
 }
 
 void rt_launch_gather_uv(const float* texcoords, const uint32_t* tex_idx, const int32_t* material_ids, const uint32_t* order,
