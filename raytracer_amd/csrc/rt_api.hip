@@ -86,6 +86,7 @@ struct rt_ctx {
   // tail of frame i (few waves left, latency-bound) overlaps the head of frame i+1
   DevBuf<uint8_t> pix_class;                   // frame-coherent scheduling hints (rt_trace.hip), shared by the frame slots
   uint64_t pix_class_key = ~0ull;
+  float last_uniforms[44] = {};                // view of the previous frame: an unchanged view keeps per-pixel hints unpromoted
   bool class_partial_reset[2] = {true, true};
   uint32_t bvh_serial = 0;                     // bumped whenever the BVH changes
   bool coherent_scheduling = true;
@@ -829,7 +830,16 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
     // PT pixels are a chain of ~50 traversals whatever their class: only hit / miss is separated there.
     p.class_t1 = 16u;
     p.class_t2 = (opts->mode == RT_MODE_PT && !p.pt_cap) ? 0xFFFFFFFFu : 0u;   // 0 = adaptive: the top class_hot_pct % of last frame's non-cheap pixels
-    p.class_hot_pct = 20u;    // measured: 20 / 30 / 40 / 50 % -> k_render 0.394 / 0.415 / 0.394 / 0.451 ms (cfg 3), 3.20 / 3.21 / 3.23 / 3.27 ms (cfg 5)
+    // A view that changed since the last frame moves the long rays by a few pixels: then a hot pixel promotes its 8x8
+    // tile's non-cheap pixels and the hot share is smaller (tools/moving_camera.py, k_render with / without hints:
+    // static view 0.397 vs 0.463 ms per-pixel, 0.414 promoted; model turning 0.25 deg per frame: per-pixel 0.462 = no
+    // gain, promoted 0.438 = +6 %; 1 deg: +7 %; 4-15 deg: +2 %).  An unchanged view (what the reference redraws all the
+    // time, script.js:865-974) keeps the sharper per-pixel classes: cfg 5 loses its whole gain when promoted (3.19 vs 3.51 ms).
+    const bool moved = std::memcmp(ctx->last_uniforms, uniforms, sizeof(float) * 44) != 0;
+    std::memcpy(ctx->last_uniforms, uniforms, sizeof(float) * 44);
+    p.class_promote = moved ? 1u : 0u;
+    if (const char* e = std::getenv("RTCORE_TILE_PROMOTE")) p.class_promote = (uint32_t)std::atoi(e);
+    p.class_hot_pct = moved ? 10u : 20u;    // unpromoted, static view: 20 / 30 / 40 / 50 % -> k_render 0.394 / 0.415 / 0.394 / 0.451 ms (cfg 3), 3.20 / 3.21 / 3.23 / 3.27 ms (cfg 5)
     if (const char* e = std::getenv("RTCORE_HOT_PCT")) p.class_hot_pct = (uint32_t)std::atoll(e);
     if (const char* e = std::getenv("RTCORE_T1")) p.class_t1 = (uint32_t)std::atoll(e);
     if (const char* e = std::getenv("RTCORE_T2")) p.class_t2 = (uint32_t)std::atoll(e);

@@ -74,6 +74,7 @@ struct RtRenderParams {
   // Frame-coherent scheduling hints (never results): cost class of every pixel as measured by the previous frame
   // (0 = cheap or unknown, 1 = normal, 2 = hot), read by k_cull, rewritten by k_render.  NULL = no hints.
   uint8_t*  pix_class;             // [local_rows*width]
+  uint32_t  class_promote;         // k_cull: a tile with a hot pixel traces all its non-cheap pixels with the hot class
   uint32_t  class_t1, class_t2;    // traversal steps: class = (steps >= t1) + (steps >= t2); t2 == 0: adaptive, see class_hist
   uint32_t* class_hist;            // [64] histogram of (steps - t1) / 4 over last frame's pixels with steps >= t1 (k_render adds, k_compact reads + clears)
   uint32_t  class_hot_pct;         // adaptive t2: the hot class is about this share of last frame's non-cheap pixels (k_compact -> list_count[2])

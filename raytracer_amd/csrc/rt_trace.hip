@@ -605,6 +605,7 @@ __global__ __launch_bounds__(TBLK) void k_cull(const RtRenderParams p) {
           cls = p.pix_class[idx];                             // last frame's hint; anything else than 1 / 2 counts as 0
         }
       }
+      if (p.class_promote && __ballot(enters && cls == 2u) != 0ull && cls == 1u) cls = 2u;   // a hot pixel makes its tile's normal pixels hot
       m[2] = __ballot(enters && cls == 2u);
       m[1] = __ballot(enters && cls == 1u);
       m[0] = __ballot(enters && cls != 1u && cls != 2u);
