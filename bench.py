@@ -59,10 +59,10 @@ def main():
     ap.add_argument("--layout", default="wide64", choices=["wide64", "aos32"])
     ap.add_argument("--encoding", default="auto", choices=["auto", "v1", "v2"],
                     help="node records: v1 = reference (f32-valued indices, < 2^24 nodes), v2 = u32 bit-casts")
-    ap.add_argument("--frames-in-flight", default="auto", choices=["auto", "1", "2"],
+    ap.add_argument("--frames-in-flight", default="auto", choices=["auto", "1", "2", "3", "4"],
                     help="asynchronous frames in flight per GPU (rtcore.h rt_set_frames_in_flight). auto = 1 on one GPU, so that every "
-                         "k_render launch runs alone and its duration is the kernel's own (roofline), 2 with N > 1, where a rank's "
-                         "share of the frame is small and mostly tail")
+                         "k_render launch runs alone and its duration is the kernel's own (roofline), 3 with N > 1, where a rank's "
+                         "share of the frame is small and mostly tail (3 frame streams + the context stream = the 4 hardware queues)")
     ap.add_argument("--no-fif2", action="store_true", help="skip the extra two-frames-in-flight loop at N = 1")
     ap.add_argument("--no-texture", action="store_true",
                     help="shade with the reference's constant albedo (compute.wgsl:372) instead of the materials + textures of cfg 3")
@@ -132,7 +132,7 @@ def main():
     # camera (B) of SURVEY §8d: pos (0,0,1.3), default sliders
     U = rt.make_uniforms(W, H, cam_pos=(0.0, 0.0, 1.3))
     base = rt.render_opts(mode=mode, gi_samples=args.spp, layout=layout, flags=tflag)
-    fif = (1 if world == 1 else 2) if args.frames_in_flight == "auto" else int(args.frames_in_flight)
+    fif = (1 if world == 1 else 3) if args.frames_in_flight == "auto" else int(args.frames_in_flight)
     frame = rdist.ShardedFrame(rdist.GpuBackend(ctx, device, frames_in_flight=fif), W, H, rank, world, base)
 
     # one counted launch (untimed): rays + work counters of this rank's share of the frame

@@ -276,18 +276,18 @@ int rt_set_coherent_scheduling(rt_ctx* ctx, int on);
 /* Frames in flight (no counterpart in the reference, whose rAF loop submits one frame at a time, script.js:865-974).
  * A persistent traversal launch ends with a tail in which a few waves finish their last pixels (each pixel is a
  * chain of dependent node fetches), and small frames - a 1/8 stripe share of a 4K frame - are mostly tail.
- * With n = 2, rt_render_device calls that do not ask for stats alternate between two internal frame streams (own
- * scratch each), so the tail of one frame overlaps the head of the next.  Ordering rules in that mode:
+ * With n = 2 .. 4, rt_render_device calls that do not ask for stats rotate over n internal frame streams (own
+ * scratch each), so the tail of one frame overlaps the head of the next (small frames - a stripe share - profit from more).  Ordering rules in that mode:
  *   - a frame starts after everything queued on rt_stream() before its rt_render_device call;
  *   - rt_stream() itself does NOT wait for such frames until the next entry point that needs their results on it
  *     (rt_synchronize, any build / import / readback call, a rt_render* that returns stats);
  *   - rt_deinterleave_device never waits for frames (it consumes gathered data, not this context's frames);
- *   - rt_frames_join(ctx, keep_latest) makes rt_stream() wait for the frames issued so far, except the most recent one
- *     when keep_latest = 1: a host that queues frame i first and then, on rt_stream(), the collective and the
+ *   - rt_frames_join(ctx, keep_latest) makes rt_stream() wait for the frames issued so far, except the keep_latest most
+ *     recent ones: a host that queues frame i first and then, on rt_stream(), the collective and the
  *     de-interleave of frame i-1 keeps two frames overlapping (raytracer_amd/dist.py does exactly that).
  * n = 1 (default): every frame runs on rt_stream(), in order. */
-int rt_set_frames_in_flight(rt_ctx* ctx, int n /* 1 or 2 */);
-int rt_frames_join(rt_ctx* ctx, int keep_latest /* 0 or 1 */);
+int rt_set_frames_in_flight(rt_ctx* ctx, int n /* 1 .. 4 */);
+int rt_frames_join(rt_ctx* ctx, int keep_latest /* 0 .. 3 */);
 
 int rt_synchronize(rt_ctx* ctx);
 /* The hipStream_t the context launches on (as void*), so hosts can order their own work. */

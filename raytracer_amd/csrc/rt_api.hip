@@ -78,23 +78,25 @@ struct rt_ctx {
   uint32_t n_textures = 0;                              // highest set slot + 1
 
   // render scratch, one set per frame slot (slot 0 = the context stream; slots 0/1 alternate with two frames in flight)
-  DevBuf<uint32_t> r_tile_counter[2], r_list[2];
-  DevBuf<float4> pt_recs[2];                   // PT split records (rt_trace.hip), per frame slot
-  DevBuf<float> pt_terms[2];
-  DevBuf<unsigned long long> r_stats[2];
+  static constexpr int MAX_FIF = 4;            // frame slots (rt_set_frames_in_flight)
+  DevBuf<uint32_t> r_tile_counter[MAX_FIF], r_list[MAX_FIF];
+  DevBuf<float4> pt_recs[MAX_FIF];             // PT split records (rt_trace.hip), per frame slot
+  DevBuf<float> pt_terms[MAX_FIF];
+  DevBuf<unsigned long long> r_stats[MAX_FIF];
   // frames in flight (rt_set_frames_in_flight): asynchronous frames alternate between two frame streams so that the
   // tail of frame i (few waves left, latency-bound) overlaps the head of frame i+1
   DevBuf<uint8_t> pix_class;                   // frame-coherent scheduling hints (rt_trace.hip), shared by the frame slots
   uint64_t pix_class_key = ~0ull;
   float last_uniforms[44] = {};                // view of the previous frame: an unchanged view keeps per-pixel hints unpromoted
-  bool class_partial_reset[2] = {true, true};
+  bool class_partial_reset[MAX_FIF] = {true, true, true, true};
   uint32_t bvh_serial = 0;                     // bumped whenever the BVH changes
   bool coherent_scheduling = true;
   int frames_in_flight = 1;
-  hipStream_t fstream[2] = {nullptr, nullptr};
-  hipEvent_t f_done[2] = {nullptr, nullptr};   // recorded behind each async frame on its frame stream
+  hipStream_t fstream[MAX_FIF] = {};
+  hipEvent_t f_done[MAX_FIF] = {};             // recorded behind each async frame on its frame stream
   hipEvent_t f_main = nullptr;                 // main-stream marker the frame streams wait on
-  bool f_pending[2] = {false, false};          // f_done[k] recorded and not yet joined into the context stream
+  bool f_pending[MAX_FIF] = {};                // f_done[k] recorded and not yet joined into the context stream
+  uint32_t f_seq[MAX_FIF] = {};                // issue number of the frame pending in slot k
   uint32_t f_count = 0;
   DevBuf<uint8_t> o_rgba;
   DevBuf<uint32_t> o_tri;
@@ -122,7 +124,7 @@ struct DeviceGuard {   // makes the context's device current for the duration of
 
 // Make the context stream wait for every asynchronous frame still running on a frame stream.
 int join_frames(rt_ctx* ctx) {
-  for (int k = 0; k < 2; ++k)
+  for (int k = 0; k < rt_ctx::MAX_FIF; ++k)
     if (ctx->f_pending[k]) {
       hipError_t e = hipStreamWaitEvent(ctx->stream, ctx->f_done[k], 0);
       if (e != hipSuccess) return ctx->hipfail("hipStreamWaitEvent(frame)", e);
@@ -227,7 +229,7 @@ extern "C" void rt_destroy(rt_ctx* ctx) {
   ctx->texcoords.release(); ctx->tri_uv.release(); ctx->tidx.release(); ctx->matid.release(); ctx->materials.release();
   for (auto& t : ctx->texels) t.release();
   ctx->tex_table.release();
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < rt_ctx::MAX_FIF; ++k) {
     ctx->r_tile_counter[k].release(); ctx->r_list[k].release(); ctx->r_stats[k].release(); ctx->pt_recs[k].release(); ctx->pt_terms[k].release();
     if (ctx->fstream[k]) { (void)hipStreamSynchronize(ctx->fstream[k]); (void)hipStreamDestroy(ctx->fstream[k]); }
     if (ctx->f_done[k]) (void)hipEventDestroy(ctx->f_done[k]);
@@ -763,11 +765,12 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
   // Frame slot + stream.  Synchronous frames (stats wanted) and contexts with one frame in flight use the context
   // stream and slot 0 after joining whatever is still running; asynchronous frames with two in flight alternate
   // between the two frame streams, each behind everything queued on the context stream so far.
-  const bool overlap = ctx->frames_in_flight == 2 && out == nullptr;
+  const bool overlap = ctx->frames_in_flight >= 2 && out == nullptr;
   int slot = 0;
   hipStream_t s = ctx->stream;
   if (overlap) {
-    slot = (int)(ctx->f_count++ & 1u);
+    slot = (int)(ctx->f_count % (uint32_t)ctx->frames_in_flight);
+    ctx->f_seq[slot] = ctx->f_count++;
     s = ctx->fstream[slot];
     HIPCHK(hipEventRecord(ctx->f_main, ctx->stream));
     HIPCHK(hipStreamWaitEvent(s, ctx->f_main, 0));
@@ -813,10 +816,10 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
     const size_t n_px = (size_t)p.local_rows * p.width;
     if (key != ctx->pix_class_key || ctx->pix_class.n < n_px) {
       HIPCHK(hipStreamSynchronize(ctx->stream));   // frames in flight may still use the old array
-      for (int k = 0; k < 2; ++k) if (ctx->fstream[k]) HIPCHK(hipStreamSynchronize(ctx->fstream[k]));
+      for (int k = 0; k < rt_ctx::MAX_FIF; ++k) if (ctx->fstream[k]) HIPCHK(hipStreamSynchronize(ctx->fstream[k]));
       HIPCHK(ctx->pix_class.ensure(n_px));
       HIPCHK(hipMemsetAsync(ctx->pix_class.p, 0, n_px, s));
-      ctx->class_partial_reset[0] = ctx->class_partial_reset[1] = true;
+      for (bool& r : ctx->class_partial_reset) r = true;
       ctx->pix_class_key = key;
     }
     if (ctx->class_partial_reset[slot]) {
@@ -883,28 +886,27 @@ extern "C" int rt_set_coherent_scheduling(rt_ctx* ctx, int on) {
 
 extern "C" int rt_set_frames_in_flight(rt_ctx* ctx, int n) {
   if (!ctx) return RT_ERR_INVALID;
-  if (n != 1 && n != 2) return ctx->fail(RT_ERR_INVALID, "rt_set_frames_in_flight: 1 or 2");
+  if (n < 1 || n > rt_ctx::MAX_FIF) return ctx->fail(RT_ERR_INVALID, "rt_set_frames_in_flight: 1 .. 4");
   DeviceGuard g(ctx->device);
   JOIN_FRAMES();
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (n == 2 && !ctx->fstream[0]) {
-    for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < n && n >= 2; ++k)
+    if (!ctx->fstream[k]) {
       HIPCHK(hipStreamCreateWithFlags(&ctx->fstream[k], hipStreamNonBlocking));
       HIPCHK(hipEventCreateWithFlags(&ctx->f_done[k], hipEventDisableTiming));
     }
-    HIPCHK(hipEventCreateWithFlags(&ctx->f_main, hipEventDisableTiming));
-  }
+  if (n >= 2 && !ctx->f_main) HIPCHK(hipEventCreateWithFlags(&ctx->f_main, hipEventDisableTiming));
   ctx->frames_in_flight = n;
   return RT_OK;
 }
 
 extern "C" int rt_frames_join(rt_ctx* ctx, int keep_latest) {
   if (!ctx) return RT_ERR_INVALID;
-  if (keep_latest < 0 || keep_latest > 1) return ctx->fail(RT_ERR_INVALID, "rt_frames_join: keep_latest is 0 or 1");
+  if (keep_latest < 0 || keep_latest >= rt_ctx::MAX_FIF) return ctx->fail(RT_ERR_INVALID, "rt_frames_join: keep_latest is 0 .. 3");
   DeviceGuard g(ctx->device);
-  const int latest = (int)((ctx->f_count - 1u) & 1u);     // slot of the most recent asynchronous frame
-  for (int k = 0; k < 2; ++k) {
-    if (!ctx->f_pending[k] || (keep_latest == 1 && k == latest)) continue;
+  for (int k = 0; k < rt_ctx::MAX_FIF; ++k) {
+    // the keep_latest most recently issued frames stay un-joined: issue numbers f_count - keep_latest .. f_count - 1
+    if (!ctx->f_pending[k] || ctx->f_count - ctx->f_seq[k] <= (uint32_t)keep_latest) continue;
     HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->f_done[k], 0));
     ctx->f_pending[k] = false;
   }

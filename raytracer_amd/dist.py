@@ -33,8 +33,8 @@ class GpuBackend:
     """Renders through librtcore.so into torch-owned device buffers (no host copies)."""
 
     def __init__(self, ctx, device, frames_in_flight=2):
-        self.ctx, self.device = ctx, device
-        ctx.set_frames_in_flight(frames_in_flight)     # the tail of frame i overlaps the head of frame i+1 (rtcore.h)
+        self.ctx, self.device, self.fif = ctx, device, max(1, int(frames_in_flight))
+        ctx.set_frames_in_flight(self.fif)     # the tail of frame i overlaps the head of frame i+1 (rtcore.h)
         # the context's own HIP stream, seen from torch: the collective and the de-interleave of a frame are queued on it
         self.ext = torch.cuda.ExternalStream(ctx.stream(), device=device)
 
@@ -47,9 +47,9 @@ class GpuBackend:
 
     def gather(self, gathered, packed, keep_latest):
         """all-gather of a finished frame's stripes on the context stream: the stream first waits for that frame
-        (all asynchronous frames issued so far, except the most recent one when keep_latest), then torch queues the
+        (all asynchronous frames issued so far, except the keep_latest most recent ones), then torch queues the
         collective behind it (on this stream, or on its own communication stream ordered against it)."""
-        self.ctx.frames_join(1 if keep_latest else 0)
+        self.ctx.frames_join(int(keep_latest))
         with torch.cuda.stream(self.ext):
             dist.all_gather_into_tensor(gathered, packed)
 
@@ -103,7 +103,7 @@ class ShardedFrame:
     alternate; frame i+2 reuses pair i only after all-gather(i) (a frame starts behind everything queued on the
     context stream before it)."""
 
-    DEPTH = 2
+    DEPTH = 2      # ring of packed / gathered buffers and frames kept un-gathered (more with GpuBackend(frames_in_flight > 2))
 
     def __init__(self, backend, width, height, rank, world, base_opts=None, force_collective=False):
         """force_collective: run the gather + de-interleave leg even at world == 1 (tests the stream plumbing on one GPU)."""
@@ -114,13 +114,14 @@ class ShardedFrame:
         self.opts = render_opts(mode=o.mode, gi_samples=o.gi_samples, gi_bounces=o.gi_bounces, soft_samples=o.soft_samples,
                                 max_stack=o.max_stack, layout=o.layout, flags=o.flags,
                                 stripe_rows=STRIPE_ROWS if world > 1 else 0, stripe_rank=rank, stripe_world=world)
-        depth = self.DEPTH        # also without a collective: two frames may be in flight and must not share an output
+        # one output buffer per frame that can be in flight (also without a collective), at least two
+        depth = max(self.DEPTH, getattr(backend, "fif", self.DEPTH))
         self.packed_ring = [backend.alloc(self.rpr, width) for _ in range(depth)]
         self.gathered_ring = [backend.alloc(self.rpr * world, width) for _ in range(depth)] if self.collective else None
         self.packed = self.packed_ring[0]
         self.image = backend.alloc(height, width) if self.collective else self.packed
         self.n_steps = 0
-        self.pending = None            # slot of the frame that is rendered (or rendering) but not yet gathered
+        self.pending = []              # ring slots of the frames rendered (or rendering) but not yet gathered, oldest first
 
     def _exchange(self, slot, keep_latest):
         packed, gathered = self.packed_ring[slot], self.gathered_ring[slot]
@@ -141,17 +142,16 @@ class ShardedFrame:
         if not self.collective:
             self.image = packed                            # world == 1: the packed rows are the frame
             return st
-        if self.pending is not None:                       # the previous frame, while this one is traversing
-            self._exchange(self.pending, keep_latest=True)
-        self.pending = slot
+        self.pending.append(slot)
+        while len(self.pending) >= len(self.packed_ring):  # the oldest frame, while the newer ones are traversing
+            self._exchange(self.pending.pop(0), keep_latest=len(self.pending))
         if want_stats:
             self.finish_exchange()
         return st
 
     def finish_exchange(self):
-        if self.pending is not None:
-            self._exchange(self.pending, keep_latest=False)
-            self.pending = None
+        while self.pending:
+            self._exchange(self.pending.pop(0), keep_latest=len(self.pending))
 
     def finish(self):
         if self.collective:

@@ -29,7 +29,7 @@ def nccl_world1():
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("fif", [1, 2])
+@pytest.mark.parametrize("fif", [1, 2, 4])
 def test_async_frames_with_forced_collective(gpu_ctx, rt, plane_mesh, nccl_world1, fif):
     import torch
 
@@ -69,7 +69,7 @@ def test_two_frames_in_flight_without_collective(gpu_ctx, rt, plane_mesh):
              dict(PLANE_VIEW, cam_pos=(-0.2, 0.1, 1.0))]
     refs = [gpu_ctx.render(rt.make_uniforms(w, h, **v), opts, want=("rgba8",))[0]["rgba8"] for v in views]
     assert not np.array_equal(refs[0], refs[1])
-    frame = rdist.ShardedFrame(rdist.GpuBackend(gpu_ctx, dev, frames_in_flight=2), w, h, 0, 1, opts)
+    frame = rdist.ShardedFrame(rdist.GpuBackend(gpu_ctx, dev, frames_in_flight=3), w, h, 0, 1, opts)
     for rounds in range(3):
         imgs = []
         for k in range(8):

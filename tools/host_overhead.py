@@ -25,9 +25,9 @@ def main():
     ctx.set_mesh(m)
     ctx.build_lbvh()
     dev = torch.device("cuda:0")
-    for (w, h) in ((64, 64), (3840, 272), (3840, 2160)):
+    for (w, h) in ((3840, 272), (3840, 544), (3840, 2160)):
         U = rt.make_uniforms(w, h, cam_pos=(0.0, 0.0, 1.3))
-        for coll, fif in ((False, 1), (False, 2), (True, 1), (True, 2)):
+        for coll, fif in ((False, 1), (False, 2), (False, 3), (False, 4), (True, 2), (True, 3), (True, 4)):
             f = rdist.ShardedFrame(rdist.GpuBackend(ctx, dev, frames_in_flight=fif), w, h, 0, 1, rt.render_opts(mode=rt.MODE_SHADOW), force_collective=coll)
             for _ in range(20):
                 f.step(U, want_stats=False)
