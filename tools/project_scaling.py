@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Projection of the N-GPU frame loop from ONE GPU: rank r's share of the cfg-3 frame (16-row stripes, stripe s -> rank s % N)
+rendered in the real loop (frames in flight, gather leg forced on through a world-1 RCCL group, de-interleave), timed per
+frame.  The N-GPU rate is bounded by the slowest rank: projected speed-up = t(N=1) / max_r t_r(N).  What this cannot show:
+the xGMI transfer itself (33 MB / N per rank and frame, << 0.1 ms) and cross-rank skew."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import torch.distributed as dist
+
+import raytracer_amd as rt
+from raytracer_amd import dist as rdist, scenes
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29557", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+ctx = rt.Context(0)
+m = rt.normalize_mesh(scenes.s1m())
+ctx.set_mesh(m); ctx.set_surface(m); ctx.build_lbvh()
+scenes.bind_standin_surface(ctx, m)
+dev = torch.device("cuda:0")
+W, H = 3840, 2160
+U = rt.make_uniforms(W, H, cam_pos=(0.0, 0.0, 1.3))
+base = rt.render_opts(mode=rt.MODE_SHADOW, flags=rt.FLAG_TEXTURED)
+
+
+def run(world, rank, fif, n=200):
+    f = rdist.ShardedFrame(rdist.GpuBackend(ctx, dev, frames_in_flight=fif), W, H, 0, 1, base, force_collective=world > 1)
+    if world > 1:                    # this rank's stripes, packed; the world-1 group gathers just them
+        rpr = rdist.rows_per_rank(H, world)
+        f.rpr = rpr
+        f.opts = rt.render_opts(mode=base.mode, flags=base.flags, stripe_rows=16, stripe_rank=rank, stripe_world=world)
+        f.packed_ring = [f.b.alloc(rpr, W) for _ in f.packed_ring]
+        f.gathered_ring = [f.b.alloc(rpr, W) for _ in f.gathered_ring]
+        f.image = f.b.alloc(rpr, W)
+        f.h = rpr                    # de-interleave of a 1-rank "image" of rpr rows
+    for _ in range(20):
+        f.step(U, want_stats=False)
+    f.finish()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        f.step(U, want_stats=False)
+    f.finish()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+t1 = run(1, 0, 1)
+print(f"N=1 (one frame in flight, as bench.py): {t1:.4f} ms/frame", flush=True)
+for world in (2, 4, 8):
+    ts = [run(world, r, 3) for r in range(world)]
+    print(f"N={world}: per-rank ms/frame {[round(t, 4) for t in ts]} -> slowest {max(ts):.4f}, projected speed-up {t1 / max(ts):.2f}x "
+          f"({t1 / max(ts) / world * 100:.0f} % of linear)", flush=True)
+dist.destroy_process_group()
+ctx.close()
