@@ -222,7 +222,7 @@ def main():
         }
         if fif2 is not None:
             out["two_frames_in_flight"] = fif2
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args, mesh, U, mode, textured)
         print(json.dumps(out), flush=True)
     if world > 1:
