@@ -128,3 +128,67 @@ def test_render_rows_and_threads_are_consistent(oracle, rt):
     rows = list(range(3, 30, 7))
     assert np.array_equal(d["rgba8"][rows], a["rgba8"][rows]) and sd["pixels"] == len(rows) * 40
     assert (a["hit_tri"] != 0xFFFFFFFF).any()
+
+
+def _brute_force_closest(tri, ro, rd):
+    """Front-face Moeller-Trumbore (compute.wgsl:107-132 predicate) of every ray against EVERY triangle, float64, no BVH."""
+    v0, e1, e2 = tri[:, 0], tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]
+    best_t = np.full(len(ro), np.inf)
+    best_i = np.full(len(ro), -1, np.int64)
+    for r in range(len(ro)):
+        p = np.cross(rd[r], e2)
+        det = np.einsum("ij,ij->i", e1, p)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = 1.0 / det
+            s = ro[r] - v0
+            u = np.einsum("ij,ij->i", s, p) * inv
+            q = np.cross(s, e1)
+            v = (q @ rd[r]) * inv
+            t = np.einsum("ij,ij->i", e2, q) * inv
+        ok = (det > 1e-10) & (u >= 0) & (v >= 0) & (u + v <= 1) & (t > 1e-10)
+        if ok.any():
+            t = np.where(ok, t, np.inf)
+            best_i[r] = int(np.argmin(t))
+            best_t[r] = t[best_i[r]]
+    return best_i, best_t
+
+
+@pytest.mark.parametrize("scene", ["plane", "soup"])
+def test_traversal_finds_the_brute_force_closest_hit(oracle, rt, plane_mesh, scene):
+    """Ground truth that does not share the tree code: with a stack deep enough that nothing is dropped, the oracle's BVH
+    traversal must return, for every pixel, the closest front-facing triangle of an exhaustive float64 test of all triangles."""
+    if scene == "plane":
+        mesh = plane_mesh
+        U = rt.make_uniforms(48, 32, cam_pos=(0.0, 0.0, 1.3), rot_deg=(-90.0, 0.0, 0.0), scale=(2.5, 2.5, 2.5))
+    else:
+        mesh = random_soup(3000, 31, scale=1.0, size=0.3)
+        mesh.positions -= 0.5
+        U = rt.make_uniforms(48, 32, cam_pos=(0.1, -0.05, 1.4), yaw=0.05)
+    b = oracle.build_lbvh(mesh.positions, mesh.normals, mesh.vert_idx, mesh.norm_idx)
+    out, st = oracle.render(b["nodes"], b["tri_pos"], b["tri_nor"], U, mode=0, max_stack=64)
+    assert st["stack_drops"] == 0
+    w, h = 48, 32
+    # the rays of cs_main in float64 from the same 44 uniform floats (compute.wgsl:419-432, :351-358)
+    Ud = U.astype(np.float64)
+    M = Ud[20:36].reshape(4, 4).T                                   # column-major storage
+    ys, xs = np.mgrid[0:h, 0:w]
+    sx, sy = (xs + 0.5) / w * 2 - 1, (ys + 0.5) / h * 2 - 1
+    rd_w = Ud[8:11] * sx[..., None] + Ud[12:15] * sy[..., None] + Ud[16:19]
+    rd_w /= np.linalg.norm(rd_w, axis=-1, keepdims=True)
+    ro = (M @ np.append(Ud[0:3], 1.0))[:3]
+    rd = rd_w.reshape(-1, 3) @ M[:3, :3].T
+    rd /= np.linalg.norm(rd, axis=-1, keepdims=True)
+    tri = b["tri_pos"][:, :, :3].astype(np.float64)                 # BVH order = the ids the traversal reports
+    bi, bt = _brute_force_closest(tri, np.tile(ro, (w * h, 1)), rd)
+    got_i = out["hit_tri"].reshape(-1).astype(np.int64)
+    got_i[got_i == 0xFFFFFFFF] = -1
+    got_t = out["hit_t"].reshape(-1).astype(np.float64)
+    hit = bi >= 0
+    assert hit.mean() > 0.15
+    # f32 vs f64 rays differ in the last bits: allow disagreement only where a second triangle is within 1e-5 of the winner (edges)
+    same = got_i == bi
+    close = np.abs(got_t - bt) <= 1e-5 * np.maximum(1.0, np.abs(bt))
+    assert np.all((got_i >= 0) == hit) or np.mean((got_i >= 0) != hit) < 0.01      # silhouette pixels may flip
+    both = hit & (got_i >= 0)
+    assert np.all(close[both]), "hit distance differs from the exhaustive test"
+    assert same[both].mean() > 0.98
