@@ -54,7 +54,9 @@ def main():
     ap.add_argument("--scene", default="s1m")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
-    ap.add_argument("--mode", default="shadow", choices=["primary", "shadow", "pt"])
+    ap.add_argument("--mode", default="shadow", choices=["primary", "shadow", "pt", "frag-web", "frag-root"],
+                    help="frag-web / frag-root: the older fragment shaders (web/shader.wgsl, shader.wgsl; SURVEY §8f-4) with the "
+                         "constants they are written with, constant albedo")
     ap.add_argument("--spp", type=int, default=32)
     ap.add_argument("--layout", default="wide64", choices=["wide64", "aos32"])
     ap.add_argument("--encoding", default="auto", choices=["auto", "v1", "v2"],
@@ -90,11 +92,13 @@ def main():
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
 
-    mode = dict(primary=rt.MODE_PRIMARY, shadow=rt.MODE_SHADOW, pt=rt.MODE_PT)[args.mode]
+    mode = {"primary": rt.MODE_PRIMARY, "shadow": rt.MODE_SHADOW, "pt": rt.MODE_PT, "frag-web": rt.MODE_FRAG_WEB,
+            "frag-root": rt.MODE_FRAG_ROOT}[args.mode]
+    frag = mode in (rt.MODE_FRAG_WEB, rt.MODE_FRAG_ROOT)
     layout = dict(wide64=rt.LAYOUT_WIDE64, aos32=rt.LAYOUT_AOS32)[args.layout]
     W, H = args.width, args.height
     ctx = rt.Context(local)
-    textured = not args.no_texture
+    textured = not args.no_texture and not frag
     tflag = rt.FLAG_TEXTURED if textured else 0
 
     # ---- hot path 1: build once on rank 0 (timed separately), replicate with RCCL
@@ -131,12 +135,16 @@ def main():
 
     # camera (B) of SURVEY §8d: pos (0,0,1.3), default sliders
     U = rt.make_uniforms(W, H, cam_pos=(0.0, 0.0, 1.3))
-    base = rt.render_opts(mode=mode, gi_samples=args.spp, layout=layout, flags=tflag)
+    shade = rt.render_opts_for_mode(mode)      # sample counts / stack depth the shader file is written with
+    if not frag:
+        shade.gi_samples = args.spp
+    shade = dict(gi_samples=shade.gi_samples, gi_bounces=shade.gi_bounces, soft_samples=shade.soft_samples, max_stack=shade.max_stack)
+    base = rt.render_opts(mode=mode, layout=layout, flags=tflag, **shade)
     fif = (1 if world == 1 else 3) if args.frames_in_flight == "auto" else int(args.frames_in_flight)
     frame = rdist.ShardedFrame(rdist.GpuBackend(ctx, device, frames_in_flight=fif), W, H, rank, world, base)
 
     # one counted launch (untimed): rays + work counters of this rank's share of the frame
-    copts = rt.render_opts(mode=mode, gi_samples=args.spp, layout=layout, flags=rt.FLAG_COUNT_WORK | tflag,
+    copts = rt.render_opts(mode=mode, layout=layout, flags=rt.FLAG_COUNT_WORK | tflag, **shade,
                            stripe_rows=frame.opts.stripe_rows, stripe_rank=rank, stripe_world=world)
     cst = ctx.render_device(U, copts, d_rgba8=frame.packed.data_ptr())
     my_rays = cst["rays_primary"] + cst["rays_shadow"] + cst["rays_bounce"]
@@ -197,7 +205,9 @@ def main():
         # roofline of the dominant kernel (traversal): this rank's algorithmic bytes / its average launch duration
         achieved = my_bytes / (trav_ms * 1e-3) / 1e9 if trav_ms > 0 else 0.0
         what = {"primary": "primary rays only", "shadow": "primary + 4 soft shadow rays",
-                "pt": f"full computeLighting_optimized: GI {args.spp} spp x 3 bounces + 4 soft shadow rays per vertex"}[args.mode]
+                "pt": f"full computeLighting_optimized: GI {args.spp} spp x 3 bounces + 4 soft shadow rays per vertex",
+                "frag-web": "web/shader.wgsl computeLighting_optimized: GI 32 x 3 bounces, 8-tap Poisson-disk light per vertex",
+                "frag-root": "shader.wgsl computeLighting_optimized: 16 fixed directions x 1 bounce (roulette 0.9), 8-tap Poisson-disk light"}[args.mode]
         scene_txt = {"s1m": "cfg3: S1M closed-form icosphere stand-in for dragon.obj",
                      "s70k": "cfg1-2: S70k closed-form icosphere stand-in for bunny.obj"}.get(
                          args.scene, f"cfg5: {args.scene[7:]} copies of S1M on a lattice, flattened")
@@ -223,7 +233,7 @@ def main():
         if fif2 is not None:
             out["two_frames_in_flight"] = fif2
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(args, mesh, U, mode, textured)
+            out["cpu_baseline"] = cpu_baseline(args, mesh, U, mode, textured, shade)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -248,7 +258,7 @@ def pmc_traffic(args, world, textured):
     return t.get("k_render_hbm_bytes_per_launch") if same else None
 
 
-def cpu_baseline(args, mesh, U, mode, textured):
+def cpu_baseline(args, mesh, U, mode, textured, shade):
     """The scalar oracle ("port") on the host cores, on a bounded sample of the same frame:
     every k-th row of the 4K image, k chosen so that the sample takes ~10-30 s of CPU time."""
     from oracle import binding as oracle     # checker / baseline only — never on the product path
@@ -262,7 +272,7 @@ def cpu_baseline(args, mesh, U, mode, textured):
                               [scenes.procedural_texture(2048, 0), scenes.procedural_texture(1024, 1)])
     H = args.height
     # probe: 8 rows spread over the frame
-    _, st = oracle.render(b["nodes"], b["tri_pos"], b["tri_nor"], U, mode=mode, gi_samples=args.spp, rows=(0, H, max(1, H // 8)),
+    _, st = oracle.render(b["nodes"], b["tri_pos"], b["tri_nor"], U, mode=mode, **shade, rows=(0, H, max(1, H // 8)),
                           n_threads=cores, want=(), encoding=enc, surface=surf)
     per_row = max(st["seconds"] / max(1, len(range(0, H, max(1, H // 8)))), 1e-6)
     n_rows = int(min(H, max(8, args.cpu_seconds / per_row)))
@@ -272,7 +282,7 @@ def cpu_baseline(args, mesh, U, mode, textured):
     secs = 0.0
     reps = 0
     while reps < 2 or (secs * cores < args.cpu_seconds and reps < 64):
-        _, st = oracle.render(b["nodes"], b["tri_pos"], b["tri_nor"], U, mode=mode, gi_samples=args.spp, rows=(0, H, step),
+        _, st = oracle.render(b["nodes"], b["tri_pos"], b["tri_nor"], U, mode=mode, **shade, rows=(0, H, step),
                               n_threads=cores, want=(), encoding=enc, surface=surf)
         rays += st["rays_primary"] + st["rays_shadow"] + st["rays_bounce"]
         secs += st["seconds"]

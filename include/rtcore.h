@@ -156,7 +156,15 @@ int rt_load_bvh(rt_ctx* ctx, const char* path);
 /* ------------------------------------------------------------------ hot path 2: traversal + shading */
 enum { RT_MODE_PRIMARY = 0,   /* primary ray, N.L shading, no shadow rays (BASELINE cfg 1-2) */
        RT_MODE_SHADOW  = 1,   /* primary + SOFT_SAMPLES shadow rays (cfg 3) */
-       RT_MODE_PT      = 2 }; /* full computeLighting_optimized (cfg 4) */
+       RT_MODE_PT      = 2,   /* full computeLighting_optimized (cfg 4) */
+       /* The two older fragment-pipeline shaders, same node / triangle buffers and traversal loop.  They
+        * differ from compute.wgsl in the triangle test's thresholds, plain mul/add where compute.wgsl writes fma, a sky
+        * pixel (0.6, 0.8, 1, 1) on a miss, an 8-tap Poisson-disk area light (radius = lightPos.w, uniforms[7]), their RNGs
+        * and GI estimators, and the image's y direction: row 0 is the TOP framebuffer row, uv.y = 1 - (y + 0.5) / height
+        * (a rasteriser's interpolation of uv is implementation-defined in its last bits; that expression is the definition
+        * here).  Only uniforms[0..35] are read besides the resolution.  Constant albedo, RT_LAYOUT_WIDE64 only. */
+       RT_MODE_FRAG_WEB  = 3, /* web/shader.wgsl:369-440 : gi_samples x gi_bounces (32 x 3) cosine-weighted GI, bounce rays end at t >= 50 */
+       RT_MODE_FRAG_ROOT = 4 };/* shader.wgsl:387-454 : <= 16 fixed stratified directions (gi_bounces ignored), one bounce, roulette 0.9 */
 enum { RT_LAYOUT_WIDE64 = 0,  /* default: 64-byte two-child records + precomputed triangle edges */
        RT_LAYOUT_AOS32  = 1 };/* traverse the 32-byte interchange records directly (A/B baseline) */
 enum { RT_FLAG_COUNT_WORK = 1,   /* also count box/triangle tests (slower; for parity + roofline bytes) */
@@ -176,6 +184,8 @@ typedef struct rt_render_opts {
   int32_t stripe_world;
 } rt_render_opts;
 void rt_render_opts_default(rt_render_opts* o);
+/* the constants the shader of `mode` is written with (compute.wgsl:25-27,259; web/shader.wgsl:22-24,273; shader.wgsl:24-25,191) */
+int rt_render_opts_for_mode(rt_render_opts* o, int mode);
 
 typedef struct rt_render_stats {
   uint64_t rays_primary, rays_shadow, rays_bounce;

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 MODE_PRIMARY, MODE_SHADOW, MODE_PT = 0, 1, 2
+MODE_FRAG_WEB, MODE_FRAG_ROOT = 3, 4      # web/shader.wgsl, shader.wgsl
 
 
 class RenderOpts(C.Structure):
@@ -96,6 +97,9 @@ def lib():
         L.orc_rand2.restype = C.c_float; L.orc_rand2.argtypes = [C.c_float, C.c_float]
         L.orc_sincos.restype = None; L.orc_sincos.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.orc_pow.restype = C.c_float; L.orc_pow.argtypes = [C.c_float, C.c_float]
+        L.orc_acos.restype = C.c_float; L.orc_acos.argtypes = [C.c_float]
+        L.orc_frag_hash.restype = C.c_uint32; L.orc_frag_hash.argtypes = [C.c_int, C.c_uint32]
+        L.orc_frag_rand2.restype = C.c_float; L.orc_frag_rand2.argtypes = [C.c_int, C.c_float, C.c_float]
         L.orc_normalize_mesh.restype = None; L.orc_normalize_mesh.argtypes = [f32p, C.c_uint32]
         L.orc_centroid_bounds.restype = None; L.orc_centroid_bounds.argtypes = [f32p, u32p, C.c_uint32, f32p, f32p]
         L.orc_morton.restype = None; L.orc_morton.argtypes = [f32p, u32p, C.c_uint32, f32p, f32p, u32p]
@@ -127,6 +131,9 @@ def quantize(x): return int(lib().orc_quantize(x))
 def hash_u32(x): return int(lib().orc_hash_u32(x))
 def rand2(x, y): return float(lib().orc_rand2(x, y))
 def pow_(x, y): return float(lib().orc_pow(x, y))
+def acos(x): return float(lib().orc_acos(x))
+def frag_hash(variant, x): return int(lib().orc_frag_hash(variant, x & 0xFFFFFFFF))
+def frag_rand2(variant, sx, sy): return float(lib().orc_frag_rand2(variant, sx, sy))
 
 
 def sincos(theta):

@@ -406,6 +406,38 @@ extern "C" float orc_pow(float x, float y) {
   return ex * sc;
 }
 
+// acos for the fixed hemisphere directions of shader.wgsl:337 — pinned like sin/cos/pow above: Cephes-style asin polynomial
+// on [0, 0.5], the half-angle identity above it; plain f32 ops in a fixed order.  The argument is clamped to [-1, 1].
+extern "C" float orc_acos(float x) {
+  x = fminf(fmaxf(x, -1.0f), 1.0f);
+  const float ax = fabsf(x);
+  const bool big = ax > 0.5f;
+  const float z = big ? 0.5f * (1.0f - ax) : ax * ax;
+  const float a = big ? sqrtf(z) : ax;
+  const float p = ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z + 1.6666752422e-1f) * z * a + a;
+  if (x >= 0.0f) return big ? 2.0f * p : 1.57079632679489661923f - p;
+  return big ? 3.14159265358979323846f - 2.0f * p : 1.57079632679489661923f + p;
+}
+
+// web/shader.wgsl:176-180 (variant 1) ; shader.wgsl:320-326 (variant 2)
+extern "C" uint32_t orc_frag_hash(int variant, uint32_t x) {
+  if (variant == 1) {
+    uint32_t v = x * 747796405u + 2891336453u;
+    v = (v >> ((v >> 28) + 4u)) ^ v;
+    return v;
+  }
+  uint32_t v = x;
+  v = ((v >> 16) ^ v) * 0x45d9f3bu;
+  v = ((v >> 16) ^ v) * 0x45d9f3bu;
+  v = (v >> 16) ^ v;
+  return v;
+}
+// web/shader.wgsl:181-185 = shader.wgsl:327-331 : the seeds' BIT PATTERNS are hashed
+extern "C" float orc_frag_rand2(int variant, float sx, float sy) {
+  uint32_t xi, yi; std::memcpy(&xi, &sx, 4); std::memcpy(&yi, &sy, 4);
+  return (float)orc_frag_hash(variant, xi ^ (yi << 16)) * (1.0f / 4294967296.0f);
+}
+
 // ============================================================ traversal + shading (hot path 2)
 namespace {
 
@@ -415,6 +447,7 @@ struct Scene {
   int max_stack, gi_samples, gi_bounces, soft_samples, mode;
   int enc;   // node record encoding: 1 = v1 (reference), 2 = v2
   const orc_surface* surf;   // material/texture extension (NULL = the reference's constant albedo)
+  int frag;                  // 0 = compute.wgsl; 1 = web/shader.wgsl, 2 = shader.wgsl (older fragment shaders)
 };
 uint32_t* g_visit_counts = nullptr;        // analysis only, single-threaded use: internal steps per node
 struct Counters {
@@ -463,6 +496,24 @@ inline bool tri_intersect(V3 ro, V3 rd, V3 v0, V3 v1, V3 v2, float& t, float& u,
   return (det > 1e-10f) & (u >= 0.0f) & (v >= 0.0f) & ((u + v) <= 1.0f) & (t > 1e-10f);
 }
 
+// web/shader.wgsl:133-163 = shader.wgsl:137-167 : the older shaders' test returns early and has other thresholds
+inline bool tri_intersect_early(V3 ro, V3 rd, V3 v0, V3 v1, V3 v2, float& t, float& u, float& v) {
+  V3 e1 = v1 - v0, e2 = v2 - v0;
+  V3 p = cross(rd, e2);
+  float det = dot(e1, p);
+  if (det < 1e-8f) return false;
+  float invDet = 1.0f / det;
+  V3 s = ro - v0;
+  u = dot(s, p) * invDet;
+  if (u < 0.0f || u > 1.0f) return false;
+  V3 q = cross(s, e1);
+  v = dot(rd, q) * invDet;
+  if (v < 0.0f || u + v > 1.0f) return false;
+  t = dot(e2, q) * invDet;
+  if (t <= 1e-6f) return false;
+  return true;
+}
+
 struct Hit { float t; V3 n; uint32_t tri; float u, v; };
 
 // web/compute.wgsl:259-346 — literal transcription incl. the 12-entry stack and far-child drop (F9)
@@ -484,11 +535,12 @@ Hit traverse(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Counters& C) {
           C.tri += 1;
           if (dot(cross(vb - va, vc - va), rd) > 0.0f) continue;          // :282
           float t, u, v;
-          bool hit = tri_intersect(ro, rd, va, vb, vc, t, u, v);
+          bool hit = S.frag ? tri_intersect_early(ro, rd, va, vb, vc, t, u, v) : tri_intersect(ro, rd, va, vb, vc, t, u, v);
           if (hit && t < bestT) {                                          // :286 strict <
             bestT = t; bestTri = ti; bestU = u; bestV = v; C.hitupd += 1;
             V3 n0 = tri_n(S, ti * 3 + 0), n1 = tri_n(S, ti * 3 + 1), n2 = tri_n(S, ti * 3 + 2);
-            bestN = normalize(fma3(n2, v, fma3(n1, u, n0 * ((1.0f - u) - v))));  // :291
+            if (S.frag) bestN = normalize((n0 * ((1.0f - u) - v) + n1 * u) + n2 * v);   // web/shader.wgsl:309, shader.wgsl:227 (no fma)
+            else bestN = normalize(fma3(n2, v, fma3(n1, u, n0 * ((1.0f - u) - v))));  // :291
           }
         }
         if (sp > 0) { sp -= 1; cur = stack[sp]; } else break;
@@ -537,7 +589,7 @@ bool shadow_ray(const Scene& S, V3 ro, V3 rd, float maxDist, Counters& C) {
           V3 va = tri_p(S, ti * 3 + 0), vb = tri_p(S, ti * 3 + 1), vc = tri_p(S, ti * 3 + 2);
           C.tri += 1;
           float t, u, v;
-          bool hit = tri_intersect(ro, rd, va, vb, vc, t, u, v);
+          bool hit = S.frag ? tri_intersect_early(ro, rd, va, vb, vc, t, u, v) : tri_intersect(ro, rd, va, vb, vc, t, u, v);
           if (hit && t < maxDist) return true;
         }
         break;
@@ -690,6 +742,126 @@ Pixel compute_lighting(const Scene& S, const float* U, V3 ro_w, V3 rd_w, uint32_
   return Pixel{orc_pow(col.x, g), orc_pow(col.y, g), orc_pow(col.z, g), 1.0f, hit0.tri, hit0.t};
 }
 
+// ---------------------------------------------------------------- older fragment-pipeline shaders
+// Both files share the traversal loop, the child0-chain shadow walk and this area-light estimate with compute.wgsl's
+// predecessor constants; they differ from compute.wgsl in the triangle test (above), plain mul/add where compute.wgsl
+// writes fma, the sky colour on a miss, the RNG and the GI estimator.
+
+// web/shader.wgsl:27-36 = shader.wgsl:33-42
+const float POISSON_DISK[8][2] = {{-0.7071f, 0.7071f}, {0.7071f, 0.7071f}, {0.7071f, -0.7071f}, {-0.7071f, -0.7071f},
+                                  {-0.3536f, 0.9239f}, {0.9239f, 0.3536f}, {0.3536f, -0.9239f}, {-0.9239f, -0.3536f}};
+
+// web/shader.wgsl:240-270 = shader.wgsl:355-384
+float direct_radiance_disk(const Scene& S, V3 hit_os, V3 n_os, V3 light_os, float radius, Counters& C) {
+  V3 L = normalize(light_os - hit_os);
+  float diff = fmaxf(dot(n_os, L), 0.0f);
+  if (diff <= 0.0f) return 0.0f;
+  uint32_t occ = 0;
+  V3 perp1 = normalize(cross(n_os, L));
+  V3 perp2 = cross(L, perp1);
+  const uint32_t SOFT = (uint32_t)S.soft_samples;
+  for (uint32_t i = 0; i < SOFT; ++i) {
+    float ox = POISSON_DISK[i][0] * radius, oy = POISSON_DISK[i][1] * radius;
+    V3 samplePos = (light_os + perp1 * ox) + perp2 * oy;
+    V3 ro2 = hit_os + n_os * 0.001f;
+    V3 d = samplePos - hit_os;
+    V3 rd2 = normalize(d);
+    float sd = length(d);
+    C.rays_shadow += 1;
+    if (shadow_ray(S, ro2, rd2, sd - 0.001f, C)) occ += 1;
+  }
+  float shadowFactor = 1.0f - (float)occ / (float)SOFT;
+  return diff * shadowFactor;
+}
+
+// shader.wgsl:170-172
+inline bool is_safe_vec(V3 v) {
+  return length(v) < 1e19f && fabsf(v.x) <= 1e30f && fabsf(v.y) <= 1e30f && fabsf(v.z) <= 1e30f;
+}
+
+// shader.wgsl:45-50,334-352 : HEMI_SAMPLES[idx] = ((idx % 8) * 2 + 1) / 16, ((idx / 8) * 2 + 1) / 16 (exact in f32)
+V3 sample_hemisphere_fixed(V3 n, uint32_t idx) {
+  float sx = (float)((idx & 7u) * 2u + 1u) / 16.0f, sy = (float)((idx >> 3) * 2u + 1u) / 16.0f;
+  float theta = sx * 6.28318530718f;
+  float phi = orc_acos(sqrtf(sy));
+  float sinP, cosP, sinT, cosT;
+  orc_sincos(phi, &sinP, &cosP);
+  orc_sincos(theta, &sinT, &cosT);
+  V3 up = (fabsf(n.y) < 0.999f) ? v3(0, 1, 0) : v3(1, 0, 0);
+  V3 T = normalize(cross(up, n));
+  V3 B = cross(n, T);
+  return normalize((T * (sinP * cosT) + n * cosP) + B * (sinP * sinT));
+}
+
+// web/shader.wgsl:369-433 (variant 1) ; shader.wgsl:387-447 (variant 2).  uv = the fragment's interpolated quad coordinate.
+Pixel compute_lighting_frag(const Scene& S, const float* U, V3 ro_w, V3 rd_w, float uvx, float uvy, Counters& C) {
+  const float* model = U + 20;
+  V3 ro_os = mat_mul4(model, ro_w.x, ro_w.y, ro_w.z, 1.0f);
+  V3 rd_os = normalize(mat_mul3(model, rd_w));
+  V3 invRd = v3(1.0f / rd_os.x, 1.0f / rd_os.y, 1.0f / rd_os.z);
+  V3 light_os = mat_mul4(model, U[4], U[5], U[6], U[7]);
+  const float radius = U[7];
+  C.rays_primary += 1;
+  Hit hit0 = traverse(S, ro_os, rd_os, invRd, 1e20f, C);
+  if (hit0.t >= 1e19f) return Pixel{0.6f, 0.8f, 1.0f, 1.0f, 0xFFFFFFFFu, hit0.t};          // sky
+  V3 hit_pos = ro_os + rd_os * hit0.t;
+  V3 n_os = hit0.n;
+  const V3 albedo = v3(1.0f, 0.84f, 0.0f);
+  const float g = 1.0f / 2.2f;
+  const uint32_t GI = (uint32_t)S.gi_samples;
+  if (S.frag == 1) {
+    float directScalar = direct_radiance_disk(S, hit_pos, n_os, light_os, radius, C);
+    V3 Lo = albedo * directScalar;
+    V3 indirect = v3(0, 0, 0);
+    const uint32_t NB = (uint32_t)S.gi_bounces;
+    for (uint32_t i = 0; i < GI; ++i) {
+      V3 throughput = albedo;
+      V3 ro_b = hit_pos + n_os * 0.001f;
+      V3 n_b = n_os;
+      for (uint32_t b = 0; b < NB; ++b) {
+        float rx = orc_frag_rand2(1, (float)i, (float)b + 17.0f);
+        float ry = orc_frag_rand2(1, (float)i + 37.0f, (float)b);
+        V3 dir = sample_hemisphere(n_b, rx, ry);                       // :189-204, the same statements as compute.wgsl:153-163
+        C.rays_bounce += 1;
+        Hit h1 = traverse(S, ro_b, dir, v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z), 50.0f, C);
+        if (h1.t >= 50.0f) break;
+        V3 p1 = ro_b + dir * h1.t;
+        V3 nn1 = h1.n;
+        float dS = direct_radiance_disk(S, p1, nn1, light_os, radius, C);
+        indirect = indirect + throughput * dS;
+        throughput = throughput * albedo;
+        ro_b = p1 + nn1 * 0.001f;
+        n_b = nn1;
+      }
+    }
+    indirect = indirect / (float)GI;
+    V3 col = Lo + indirect;
+    return Pixel{orc_pow(col.x, g), orc_pow(col.y, g), orc_pow(col.z, g), 1.0f, hit0.tri, hit0.t};
+  }
+  if (!is_safe_vec(n_os)) n_os = v3(0, 1, 0);
+  float direct = direct_radiance_disk(S, hit_pos, n_os, light_os, radius, C);
+  float indirect = 0.0f;
+  const float giProb = 0.9f;
+  for (uint32_t i = 0; i < GI; ++i) {
+    float sx = uvx + (float)i * 0.031f, sy = uvy + (float)i * 0.047f;
+    if (orc_frag_rand2(2, sx, sy) > giProb) continue;
+    V3 dir1 = sample_hemisphere_fixed(n_os, i);
+    V3 ro1 = hit_pos + n_os * 0.001f;
+    C.rays_bounce += 1;
+    Hit h1 = traverse(S, ro1, dir1, v3(1.0f / dir1.x, 1.0f / dir1.y, 1.0f / dir1.z), 50.0f, C);
+    if (h1.t < 50.0f) {
+      V3 p1 = ro1 + dir1 * h1.t;
+      V3 nn1 = h1.n;
+      if (!is_safe_vec(nn1)) nn1 = v3(0, 1, 0);
+      indirect = indirect + direct_radiance_disk(S, p1, nn1, light_os, radius, C) / giProb;
+    }
+  }
+  indirect = indirect / (float)GI;
+  float k = direct + indirect * 0.6f;
+  V3 col = albedo * k;
+  return Pixel{orc_pow(col.x, g), orc_pow(col.y, g), orc_pow(col.z, g), 1.0f, hit0.tri, hit0.t};
+}
+
 inline uint8_t unorm8(float c) {  // rgba8unorm store: round(clamp(c,0,1)*255), NaN -> 0
   float v = fminf(fmaxf(c, 0.0f), 1.0f);
   return (uint8_t)sat_u32(floorf(v * 255.0f + 0.5f));
@@ -708,7 +880,16 @@ void render_pixel(const Scene& S, const float* U, uint32_t gx, uint32_t gy, uint
   uint32_t ix = sat_u32(px), iy = sat_u32(py);
   uint32_t pixelIndex = iy * w + ix;
   const uint64_t box0 = C.box;
-  Pixel p = compute_lighting(S, U, ro, rd, pixelIndex, time_h, C);
+  Pixel p;
+  if (S.frag) {
+    // vs_main / fs_main (web/shader.wgsl:61-67,165-173,435-440): the quad's uv at the fragment centre; framebuffer row 0 is
+    // the TOP row and clip-space y points up, so uv.y = 1 - (gy + 0.5) / h.  (A rasteriser's interpolation of uv is
+    // implementation-defined in its last bits; this is the definition both sides of the parity test use.)
+    const float fuy = 1.0f - uvy;
+    const float fsx = uvx * 2.0f - 1.0f, fsy = fuy * 2.0f - 1.0f;
+    V3 frd = normalize((camR * fsx + camU * fsy) + camF);
+    p = compute_lighting_frag(S, U, ro, frd, uvx, fuy, C);
+  } else p = compute_lighting(S, U, ro, rd, pixelIndex, time_h, C);
   size_t o = (size_t)gy * w + gx;
   if (g_work_img) g_work_img[o] = (uint32_t)(C.box - box0);
   if (rgba8) { rgba8[4 * o + 0] = unorm8(p.r); rgba8[4 * o + 1] = unorm8(p.g); rgba8[4 * o + 2] = unorm8(p.b); rgba8[4 * o + 3] = unorm8(p.a); }
@@ -749,7 +930,11 @@ extern "C" int orc_render(const float* nodes, uint32_t n_nodes, const float* tri
   if (o->max_stack < 1 || o->max_stack > 64 || o->row_step < 1) return -2;
   if (n_nodes == 0 || n_tri == 0) return -3;
   Scene S{nodes, n_nodes, tri_pos, tri_nor, n_tri, o->max_stack, o->gi_samples, o->gi_bounces, o->soft_samples, o->mode,
-          o->node_encoding == 2 ? 2 : 1, g_surface};
+          o->node_encoding == 2 ? 2 : 1, g_surface,
+          o->mode == ORC_MODE_FRAG_WEB ? 1 : (o->mode == ORC_MODE_FRAG_ROOT ? 2 : 0)};
+  if (S.frag && (o->soft_samples < 1 || o->soft_samples > 8)) return -4;     // POISSON_DISK has 8 entries
+  if (S.frag == 2 && (o->gi_samples < 1 || o->gi_samples > 16)) return -4;   // HEMI_SAMPLES has 16
+  if (S.frag) S.surf = nullptr;                                               // constant albedo in both files
   const uint32_t w = sat_u32(U[36]), h = sat_u32(U[37]);
   const float time_h = (float)orc_hash_u32(sat_u32(U[38]));      // compute.wgsl:444
   int r0 = std::max(0, o->row_begin), r1 = std::min<int>((int)h, o->row_end), rs = o->row_step;

@@ -18,6 +18,7 @@
  *   web/script.js:526-561           flattenForSSBO (node + triangle buffer layout)
  *   web/script.js:285-513           buildLBVH, the reference's CPU SAH builder (rt_oracle_sah.cpp)
  *   web/script.js:30-154,591-612,880-929   camera / TRS / invert4 / uniform packing
+ *   web/shader.wgsl:132-440, shader.wgsl:136-454   the two older fragment-pipeline shaders
  * Sort / Karras radix tree / refit have no reference code; they follow
  * the definitions pinned there.
  *
@@ -30,7 +31,9 @@
 extern "C" {
 #endif
 
-enum { ORC_MODE_PRIMARY = 0, ORC_MODE_SHADOW = 1, ORC_MODE_PT = 2 };
+enum { ORC_MODE_PRIMARY = 0, ORC_MODE_SHADOW = 1, ORC_MODE_PT = 2,
+       ORC_MODE_FRAG_WEB = 3,     /* web/shader.wgsl  computeLighting_optimized (:369-433) under fs_main (:435-440) */
+       ORC_MODE_FRAG_ROOT = 4 };  /* shader.wgsl      computeLighting_optimized (:387-447) under fs_main (:449-454) */
 
 typedef struct orc_render_opts {
   int32_t mode;          /* ORC_MODE_* */
@@ -64,6 +67,10 @@ float    orc_rand2(float sx, float sy);
 /* implementation-pinned transcendental kernels (DESIGN.md "numerics contract") */
 void  orc_sincos(float theta, float* s, float* c);
 float orc_pow(float x, float y);
+float orc_acos(float x);
+/* RNGs of the older shaders: web/shader.wgsl:176-185 (variant 1), shader.wgsl:320-331 (variant 2) */
+uint32_t orc_frag_hash(int variant, uint32_t x);
+float    orc_frag_rand2(int variant, float sx, float sy);
 
 /* web/script.js:207-227 — in place */
 void orc_normalize_mesh(float* pos, uint32_t n_vert);

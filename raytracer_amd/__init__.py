@@ -10,8 +10,8 @@ import ctypes as C
 import numpy as np
 
 from . import _abi
-from ._abi import (FLAG_COUNT_WORK, FLAG_TEXTURED, LAYOUT_AOS32, LAYOUT_WIDE64, MODE_PRIMARY, MODE_PT, MODE_SHADOW,  # noqa: F401
-                   NODES_V1, NODES_V2)
+from ._abi import (FLAG_COUNT_WORK, FLAG_TEXTURED, LAYOUT_AOS32, LAYOUT_WIDE64, MODE_FRAG_ROOT, MODE_FRAG_WEB,  # noqa: F401
+                   MODE_PRIMARY, MODE_PT, MODE_SHADOW, NODES_V1, NODES_V2)
 
 _L = _abi.load()          # raises ImportError when the HIP extension is not built
 
@@ -119,6 +119,19 @@ def render_opts(mode=MODE_PT, gi_samples=32, gi_bounces=3, soft_samples=4, max_s
                 stripe_rows=0, stripe_rank=0, stripe_world=1):
     return _abi.RenderOpts(mode, gi_samples, gi_bounces, soft_samples, max_stack, layout, flags, stripe_rows, stripe_rank,
                            stripe_world)
+
+
+def render_opts_for_mode(mode, **overrides):
+    """The constants the shader of `mode` is written with (rt_render_opts_for_mode), then `overrides` by field name."""
+    o = _abi.RenderOpts()
+    rc = _L.rt_render_opts_for_mode(C.byref(o), mode)
+    if rc != 0:
+        raise RtError(rc, "rt_render_opts_for_mode")
+    for k, v in overrides.items():
+        if not hasattr(o, k):
+            raise TypeError(f"rt_render_opts has no field {k!r}")
+        setattr(o, k, v)
+    return o
 
 
 def packed_rows(height, stripe_rows, rank, world):

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "librtcore.so")
 
 RT_OK, RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_IO, RT_ERR_LIMIT, RT_ERR_INTERNAL = 0, -1, -2, -3, -4, -5, -6
 MODE_PRIMARY, MODE_SHADOW, MODE_PT = 0, 1, 2
+MODE_FRAG_WEB, MODE_FRAG_ROOT = 3, 4      # the older fragment shaders: web/shader.wgsl, shader.wgsl
 LAYOUT_WIDE64, LAYOUT_AOS32 = 0, 1
 FLAG_COUNT_WORK = 1
 FLAG_TEXTURED = 2
@@ -24,7 +25,7 @@ SYMBOLS = [
     "rt_normalize_mesh", "rt_camera_default", "rt_make_uniforms",
     "rt_set_mesh", "rt_build_lbvh", "rt_get_bounds", "rt_get_morton", "rt_get_tri_order", "rt_get_counts",
     "rt_get_nodes", "rt_get_triangles", "rt_set_bvh", "rt_save_bvh", "rt_load_bvh",
-    "rt_render_opts_default", "rt_render", "rt_render_device", "rt_packed_rows", "rt_deinterleave_device",
+    "rt_render_opts_default", "rt_render_opts_for_mode", "rt_render", "rt_render_device", "rt_packed_rows", "rt_deinterleave_device",
     "rt_bvh_view_get", "rt_bvh_export_device", "rt_bvh_adopt_device", "rt_synchronize", "rt_stream",
     "rt_profile_begin", "rt_profile_end", "rt_set_node_encoding", "rt_get_node_encoding",
     "rt_set_surface", "rt_get_tri_uv", "rt_set_tri_uv", "rt_set_materials", "rt_set_texture", "rt_tri_uv_device",
@@ -135,6 +136,7 @@ def load():
         "rt_save_bvh": (C.c_int, [vp, cp]),
         "rt_load_bvh": (C.c_int, [vp, cp]),
         "rt_render_opts_default": (None, [C.POINTER(RenderOpts)]),
+        "rt_render_opts_for_mode": (C.c_int, [C.POINTER(RenderOpts), C.c_int]),
         "rt_render": (C.c_int, [vp, vp, C.POINTER(RenderOpts), vp, vp, vp, C.POINTER(RenderStats)]),
         "rt_render_device": (C.c_int, [vp, vp, C.POINTER(RenderOpts), vp, vp, vp, C.POINTER(RenderStats)]),
         "rt_packed_rows": (u32, [u32, i32, i32, i32]),

@@ -695,6 +695,16 @@ extern "C" void rt_render_opts_default(rt_render_opts* o) {
   o->layout = RT_LAYOUT_WIDE64; o->stripe_rows = 0; o->stripe_rank = 0; o->stripe_world = 1;
 }
 
+// the constants each shader file is written with
+extern "C" int rt_render_opts_for_mode(rt_render_opts* o, int mode) {
+  if (!o || mode < RT_MODE_PRIMARY || mode > RT_MODE_FRAG_ROOT) return RT_ERR_INVALID;
+  rt_render_opts_default(o);
+  o->mode = mode;
+  if (mode == RT_MODE_FRAG_WEB) { o->gi_samples = 32; o->gi_bounces = 3; o->soft_samples = 8; o->max_stack = 16; }    // web/shader.wgsl:22-24,273
+  if (mode == RT_MODE_FRAG_ROOT) { o->gi_samples = 16; o->gi_bounces = 1; o->soft_samples = 8; o->max_stack = 16; }   // shader.wgsl:24-25,191,420
+  return RT_OK;
+}
+
 extern "C" uint32_t rt_packed_rows(uint32_t height, int32_t stripe_rows, int32_t rank, int32_t world) {
   if (stripe_rows <= 0 || world <= 1) return height;
   const uint32_t sr = (uint32_t)stripe_rows;
@@ -710,7 +720,13 @@ extern "C" uint32_t rt_packed_rows(uint32_t height, int32_t stripe_rows, int32_t
 namespace {
 int check_opts(rt_ctx* ctx, const rt_render_opts* o) {
   if (!o) return ctx->fail(RT_ERR_INVALID, "render opts are NULL");
-  if (o->mode < RT_MODE_PRIMARY || o->mode > RT_MODE_PT) return ctx->fail(RT_ERR_INVALID, "bad mode");
+  if (o->mode < RT_MODE_PRIMARY || o->mode > RT_MODE_FRAG_ROOT) return ctx->fail(RT_ERR_INVALID, "bad mode");
+  if (o->mode >= RT_MODE_FRAG_WEB) {
+    if (o->soft_samples > 8) return ctx->fail(RT_ERR_INVALID, "RT_MODE_FRAG_*: soft_samples <= 8 (POISSON_DISK has 8 taps)");
+    if (o->mode == RT_MODE_FRAG_ROOT && o->gi_samples > 16) return ctx->fail(RT_ERR_INVALID, "RT_MODE_FRAG_ROOT: gi_samples <= 16 (HEMI_SAMPLES has 16 directions)");
+    if (o->layout != RT_LAYOUT_WIDE64) return ctx->fail(RT_ERR_INVALID, "RT_MODE_FRAG_*: only RT_LAYOUT_WIDE64");
+    if (o->flags & RT_FLAG_TEXTURED) return ctx->fail(RT_ERR_INVALID, "RT_MODE_FRAG_*: the older shaders have a constant albedo; RT_FLAG_TEXTURED is not defined for them");
+  }
   if (o->max_stack < 2 || o->max_stack > 32) return ctx->fail(RT_ERR_INVALID, "max_stack must be in [2,32]");
   if (o->gi_samples < 1 || o->gi_samples > 4096 || o->gi_bounces < 0 || o->gi_bounces > 64 || o->soft_samples < 1 || o->soft_samples > 64)
     return ctx->fail(RT_ERR_INVALID, "sample counts out of range");
@@ -753,6 +769,8 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
   std::memcpy(p.U, uniforms, sizeof(float) * 44);
   p.mode = opts->mode; p.gi_samples = opts->gi_samples; p.gi_bounces = opts->gi_bounces; p.soft_samples = opts->soft_samples;
   p.max_stack = opts->max_stack;
+  p.frag = opts->mode == RT_MODE_FRAG_WEB ? 1 : (opts->mode == RT_MODE_FRAG_ROOT ? 2 : 0);
+  p.miss_rgba = p.frag ? 0xFFFFCC99u : 0xFF000000u;   // rgba8unorm of (0.6, 0.8, 1, 1) (web/shader.wgsl:391) / (0, 0, 0, 1) (compute.wgsl:366)
   p.width = (uint32_t)fw; p.height = (uint32_t)fh;
   const bool striped = opts->stripe_rows > 0 && opts->stripe_world > 1;
   p.stripe_rows = striped ? opts->stripe_rows : 0; p.stripe_rank = striped ? opts->stripe_rank : 0;
@@ -832,7 +850,7 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
     // 48: 0.41, 64: 0.43; cfg 5 best at 80), so the hot threshold follows last frame's step histogram instead.
     // PT pixels are a chain of ~50 traversals whatever their class: only hit / miss is separated there.
     p.class_t1 = 16u;
-    p.class_t2 = (opts->mode == RT_MODE_PT && !p.pt_cap) ? 0xFFFFFFFFu : 0u;   // 0 = adaptive: the top class_hot_pct % of last frame's non-cheap pixels
+    p.class_t2 = ((opts->mode == RT_MODE_PT && !p.pt_cap) || p.frag) ? 0xFFFFFFFFu : 0u;   // 0 = adaptive: the top class_hot_pct % of last frame's non-cheap pixels
     // A view that changed since the last frame moves the long rays by a few pixels: then a hot pixel promotes its 8x8
     // tile's non-cheap pixels and the hot share is smaller (tools/moving_camera.py, k_render with / without hints:
     // static view 0.397 vs 0.463 ms per-pixel, 0.414 promoted; model turning 0.25 deg per frame: per-pixel 0.462 = no
@@ -848,6 +866,10 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
     if (const char* e = std::getenv("RTCORE_T2")) p.class_t2 = (uint32_t)std::atoll(e);
   }
   rt_cull_rect(p, ctx->bvh.root_box);
+  if (p.frag) {   // the fragment shaders' screen y runs the other way (uv.y = 1 - (gy + 0.5) / h): the same rectangle, rows mirrored
+    const int y0 = (int)p.height - 1 - p.cull_y1, y1 = (int)p.height - 1 - p.cull_y0;
+    p.cull_y0 = y0; p.cull_y1 = y1;
+  }
   if (out && p.n_tiles == 0) HIPCHK(hipMemsetAsync(p.stats, 0, sizeof(unsigned long long) * 8, s));
   hipEvent_t* E = nullptr;   // {frame begin, k_render begin, k_render end, frame end}
   if (ctx->prof_on) { E = &ctx->prof_ev[4 * (size_t)(ctx->prof_n % rt_ctx::PROF_RING)]; ctx->prof_n += (p.n_tiles > 0); }

@@ -114,6 +114,38 @@ RT_DEV float rt_pow(float x, float y) {
   return ex * sc;
 }
 
+// acos for the fixed hemisphere directions of shader.wgsl:337, pinned like sin/cos/pow: asin polynomial on [0, 0.5] and the
+// half-angle identity above it, plain f32 ops in a fixed order; argument clamped to [-1, 1].
+RT_DEV float rt_acos(float x) {
+  x = fminf(fmaxf(x, -1.0f), 1.0f);
+  const float ax = fabsf(x);
+  const bool big = ax > 0.5f;
+  const float z = big ? 0.5f * (1.0f - ax) : ax * ax;
+  const float a = big ? sqrtf(z) : ax;
+  const float p = ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z + 1.6666752422e-1f) * z * a + a;
+  if (x >= 0.0f) return big ? 2.0f * p : 1.57079632679489661923f - p;
+  return big ? 3.14159265358979323846f - 2.0f * p : 1.57079632679489661923f + p;
+}
+
+// RNGs of the older fragment shaders: web/shader.wgsl:176-185 (V = 1), shader.wgsl:320-331 (V = 2); the seeds' bit patterns are hashed
+template <int V>
+RT_DEV uint32_t frag_hash(uint32_t x) {
+  if (V == 1) {
+    uint32_t v = x * 747796405u + 2891336453u;
+    v = (v >> ((v >> 28) + 4u)) ^ v;
+    return v;
+  }
+  uint32_t v = x;
+  v = ((v >> 16) ^ v) * 0x45d9f3bu;
+  v = ((v >> 16) ^ v) * 0x45d9f3bu;
+  v = (v >> 16) ^ v;
+  return v;
+}
+template <int V>
+RT_DEV float frag_rand2(float sx, float sy) {
+  return (float)frag_hash<V>(__float_as_uint(sx) ^ (__float_as_uint(sy) << 16)) * (1.0f / 4294967296.0f);
+}
+
 // order-preserving float <-> uint map (total order, -0 < +0) for min/max reductions/atomics
 RT_DEV uint32_t f2ord(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 RT_DEV float ord2f(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }

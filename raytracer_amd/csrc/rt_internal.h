@@ -61,6 +61,8 @@ struct RtRenderParams {
   // inclusive pixel rectangle (global image coordinates) that conservatively contains every pixel whose
   // primary ray can enter the root box; tiles outside it are final without generating rays (x1 < x0: empty)
   int cull_x0, cull_x1, cull_y0, cull_y1;
+  int frag;                        // 0 = compute.wgsl; 1 = web/shader.wgsl, 2 = shader.wgsl (RT_MODE_FRAG_*)
+  uint32_t miss_rgba;              // pixel of a ray that hits nothing: (0,0,0,1), or the older shaders' sky
   uint8_t*  rgba8;     // packed local rows
   uint32_t* hit_tri;
   float*    hit_t;

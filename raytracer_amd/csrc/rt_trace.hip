@@ -56,7 +56,10 @@ RT_DEV void slab(V3 ro, V3 inv, V3 mn, V3 mx, float& tmin, float& tmax) {
 }
 RT_DEV bool box_hit(float tmin, float tmax, float limit) { return (tmax >= fmaxf(tmin, 0.0f)) && (tmin <= limit); }
 
-// web/compute.wgsl:107-132 with e1/e2 supplied
+// web/compute.wgsl:107-132 with e1/e2 supplied (TRI = 0).  TRI = 1: the older shaders' test (web/shader.wgsl:133-163 =
+// shader.wgsl:137-167) — the same quotients, other thresholds, and early returns whose outcome is this conjunction of
+// the negated exit conditions (a NaN passes every exit and then fails `t < best` at the caller, as it does there).
+template <int TRI>
 RT_DEV bool moller_trumbore(V3 ro, V3 rd, V3 v0, V3 e1, V3 e2, float& t, float& u, float& v) {
   const V3 p = cross3(rd, e2);
   const float det = dot3(e1, p);
@@ -66,11 +69,12 @@ RT_DEV bool moller_trumbore(V3 ro, V3 rd, V3 v0, V3 e1, V3 e2, float& t, float& 
   const V3 q = cross3(s, e1);
   v = dot3(rd, q) * invDet;
   t = dot3(e2, q) * invDet;
+  if (TRI == 1) return !(det < 1e-8f) & !((u < 0.0f) | (u > 1.0f)) & !((v < 0.0f) | ((u + v) > 1.0f)) & !(t <= 1e-6f);
   return (det > 1e-10f) & (u >= 0.0f) & (v >= 0.0f) & ((u + v) <= 1.0f) & (t > 1e-10f);
 }
 
 // ---------------------------------------------------------------- WIDE64 traversal
-template <bool COUNT>
+template <bool COUNT, int TRI = 0>
 RT_DEV Hit closest_wide(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Work& W) {
   float bestT = maxDist, bu = 0.0f, bv = 0.0f;
   uint32_t bestTri = 0xFFFFFFFFu;
@@ -127,7 +131,7 @@ RT_DEV Hit closest_wide(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Wor
       if (COUNT) W.tri += 1;
       if (!(dot3(v3(a.w, b.w, c.w), rd) > 0.0f)) {      // back-face pre-cull, compute.wgsl:282
         float t, u, v;
-        const bool hit = moller_trumbore(ro, rd, xyz(a), xyz(b), xyz(c), t, u, v);
+        const bool hit = moller_trumbore<TRI>(ro, rd, xyz(a), xyz(b), xyz(c), t, u, v);
         if (hit && t < bestT) { bestT = t; bestTri = ti; bu = u; bv = v; if (COUNT) W.hit += 1; }
       }
       leaf_j += 1;
@@ -138,7 +142,7 @@ RT_DEV Hit closest_wide(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Wor
   return h;
 }
 
-template <bool COUNT>
+template <bool COUNT, int TRI = 0>
 RT_DEV bool occluded_wide(const Scene& S, V3 ro, V3 rd, float maxDist, Work& W) {
   const V3 inv = rcp3(rd);
   {
@@ -166,7 +170,7 @@ RT_DEV bool occluded_wide(const Scene& S, V3 ro, V3 rd, float maxDist, Work& W) 
     const float4 q0 = S.tri_pre[3 * (size_t)ti + 0], q1 = S.tri_pre[3 * (size_t)ti + 1], q2 = S.tri_pre[3 * (size_t)ti + 2];
     if (COUNT) W.tri += 1;
     float t, u, v;
-    if (moller_trumbore(ro, rd, xyz(q0), xyz(q1), xyz(q2), t, u, v) && t < maxDist) return true;
+    if (moller_trumbore<TRI>(ro, rd, xyz(q0), xyz(q1), xyz(q2), t, u, v) && t < maxDist) return true;
   }
   return false;
 }
@@ -183,7 +187,7 @@ RT_DEV NodeRec fetch_node(const Scene& S, int idx) {   // compute.wgsl:68-88
   return n;
 }
 
-template <bool COUNT>
+template <bool COUNT, int TRI = 0>
 RT_DEV Hit closest_aos(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Work& W) {
   float bestT = maxDist, bu = 0.0f, bv = 0.0f;
   uint32_t bestTri = 0xFFFFFFFFu;
@@ -205,7 +209,7 @@ RT_DEV Hit closest_aos(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Work
           const V3 e1 = vb - va, e2 = vc - va;
           if (dot3(cross3(e1, e2), rd) > 0.0f) continue;
           float t, u, v;
-          const bool hit = moller_trumbore(ro, rd, va, e1, e2, t, u, v);
+          const bool hit = moller_trumbore<TRI>(ro, rd, va, e1, e2, t, u, v);
           if (hit && t < bestT) { bestT = t; bestTri = ti; bu = u; bv = v; if (COUNT) W.hit += 1; }
         }
         go_pop = true;
@@ -234,7 +238,7 @@ RT_DEV Hit closest_aos(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Work
   return h;
 }
 
-template <bool COUNT>
+template <bool COUNT, int TRI = 0>
 RT_DEV bool occluded_aos(const Scene& S, V3 ro, V3 rd, float maxDist, Work& W) {   // compute.wgsl:166-194
   const V3 inv = rcp3(rd);
   int cur = 0;
@@ -252,7 +256,7 @@ RT_DEV bool occluded_aos(const Scene& S, V3 ro, V3 rd, float maxDist, Work& W) {
         const V3 va = xyz(S.tri_pos[3 * (size_t)ti + 0]), vb = xyz(S.tri_pos[3 * (size_t)ti + 1]), vc = xyz(S.tri_pos[3 * (size_t)ti + 2]);
         if (COUNT) W.tri += 1;
         float t, u, v;
-        if (moller_trumbore(ro, rd, va, vb - va, vc - va, t, u, v) && t < maxDist) return true;
+        if (moller_trumbore<TRI>(ro, rd, va, vb - va, vc - va, t, u, v) && t < maxDist) return true;
       }
       break;
     }
@@ -261,21 +265,27 @@ RT_DEV bool occluded_aos(const Scene& S, V3 ro, V3 rd, float maxDist, Work& W) {
   return false;
 }
 
-template <int LAYOUT, bool COUNT>
+template <int LAYOUT, bool COUNT, int TRI = 0>
 RT_DEV Hit closest(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Work& W) {
-  if constexpr (LAYOUT == RT_LAYOUT_WIDE64) return closest_wide<COUNT>(S, ro, rd, inv, maxDist, W);
-  else return closest_aos<COUNT>(S, ro, rd, inv, maxDist, W);
+  if constexpr (LAYOUT == RT_LAYOUT_WIDE64) return closest_wide<COUNT, TRI>(S, ro, rd, inv, maxDist, W);
+  else return closest_aos<COUNT, TRI>(S, ro, rd, inv, maxDist, W);
 }
-template <int LAYOUT, bool COUNT>
+template <int LAYOUT, bool COUNT, int TRI = 0>
 RT_DEV bool occluded(const Scene& S, V3 ro, V3 rd, float maxDist, Work& W) {
-  if constexpr (LAYOUT == RT_LAYOUT_WIDE64) return occluded_wide<COUNT>(S, ro, rd, maxDist, W);
-  else return occluded_aos<COUNT>(S, ro, rd, maxDist, W);
+  if constexpr (LAYOUT == RT_LAYOUT_WIDE64) return occluded_wide<COUNT, TRI>(S, ro, rd, maxDist, W);
+  else return occluded_aos<COUNT, TRI>(S, ro, rd, maxDist, W);
 }
 
 // interpolated shading normal of the winning triangle (compute.wgsl:288-291), evaluated once
 RT_DEV V3 hit_normal(const Scene& S, const Hit& h) {
   const V3 n0 = xyz(S.tri_nor[3 * (size_t)h.tri + 0]), n1 = xyz(S.tri_nor[3 * (size_t)h.tri + 1]), n2 = xyz(S.tri_nor[3 * (size_t)h.tri + 2]);
   return normalize3(fma3(n2, h.v, fma3(n1, h.u, n0 * ((1.0f - h.u) - h.v))));
+}
+
+// the same normal as the older shaders write it, without fma (web/shader.wgsl:309, shader.wgsl:227)
+RT_DEV V3 hit_normal_plain(const Scene& S, const Hit& h) {
+  const V3 n0 = xyz(S.tri_nor[3 * (size_t)h.tri + 0]), n1 = xyz(S.tri_nor[3 * (size_t)h.tri + 1]), n2 = xyz(S.tri_nor[3 * (size_t)h.tri + 2]);
+  return normalize3((n0 * ((1.0f - h.u) - h.v) + n1 * h.u) + n2 * h.v);
 }
 
 // Albedo of the surface at a hit: the definition in include/rtcore.h ("material / texture shading"), the same
@@ -367,17 +377,26 @@ RT_DEV uint32_t unorm8(float c) { return sat_u32(floorf(fminf(fmaxf(c, 0.0f), 1.
 
 struct PixelOut { uint32_t rgba; uint32_t tri; float t; uint32_t cost; };   // cost: traversal steps of all closest-hit rays of the pixel
 
-struct PrimaryRay { V3 ro, rd, inv, light; uint32_t pixelIndex; };
+struct PrimaryRay { V3 ro, rd, inv, light; uint32_t pixelIndex; float uvx, uvy; };
 
 // web/compute.wgsl:419-442 (cs_main) + :351-361 (world -> object space)
-RT_DEV PrimaryRay primary_ray(const float* U, uint32_t gx, uint32_t gy, uint32_t w, uint32_t h) {
+// frag != 0: vs_main / generateRay / fs_main of the older shaders (web/shader.wgsl:61-67,166-173,435-440): the quad's uv at
+// the fragment centre — framebuffer row 0 is the top row, clip-space y points up, so uv.y = 1 - (gy + 0.5) / h — and plain
+// mul / add.  (A rasteriser's interpolation of uv is implementation-defined in its last bits; this is the definition.)
+RT_DEV PrimaryRay primary_ray(const float* U, uint32_t gx, uint32_t gy, uint32_t w, uint32_t h, int frag = 0) {
   const float uvx = ((float)gx + 0.5f) / (float)w, uvy = ((float)gy + 0.5f) / (float)h;
   const V3 ro_w = v3(U[0], U[1], U[2]);
   const float sx = __fmaf_rn(uvx, 2.0f, -1.0f), sy = __fmaf_rn(uvy, 2.0f, -1.0f);
-  const V3 rd_w = normalize3(fma3(v3(U[8], U[9], U[10]), sx, fma3(v3(U[12], U[13], U[14]), sy, v3(U[16], U[17], U[18]))));
+  V3 rd_w = normalize3(fma3(v3(U[8], U[9], U[10]), sx, fma3(v3(U[12], U[13], U[14]), sy, v3(U[16], U[17], U[18]))));
+  const float fuy = 1.0f - uvy;
+  if (frag) {
+    const float fsx = uvx * 2.0f - 1.0f, fsy = fuy * 2.0f - 1.0f;
+    rd_w = normalize3((v3(U[8], U[9], U[10]) * fsx + v3(U[12], U[13], U[14]) * fsy) + v3(U[16], U[17], U[18]));
+  }
   const float px = fminf(fmaxf(uvx * (float)w, 0.0f), (float)(w - 1));
   const float py = fminf(fmaxf(uvy * (float)h, 0.0f), (float)(h - 1));
   PrimaryRay r;
+  r.uvx = uvx; r.uvy = fuy;
   r.pixelIndex = sat_u32(py) * w + sat_u32(px);
   const float* model = U + 20;
   r.ro = mat_mul4(model, ro_w.x, ro_w.y, ro_w.z, 1.0f);
@@ -434,6 +453,129 @@ RT_DEV PixelOut shade_pixel(const Scene& S, const Shade& sh, const float* U, uin
   }
   const float d0 = direct_radiance<LAYOUT, COUNT>(S, sh, hit_pos, n_os, light_os, pixelIndex, time_h, W, R);
   const V3 col = v3(__fmaf_rn(albedo.x, d0, indirect.x), __fmaf_rn(albedo.y, d0, indirect.y), __fmaf_rn(albedo.z, d0, indirect.z));
+  const float g = 1.0f / 2.2f;
+  out.rgba = unorm8(rt_pow(col.x, g)) | (unorm8(rt_pow(col.y, g)) << 8) | (unorm8(rt_pow(col.z, g)) << 16) | 0xFF000000u;
+  return out;
+}
+
+// ---- older fragment-pipeline shaders: web/shader.wgsl (V = 1) and the root shader.wgsl (V = 2) ------------
+// Same traversal loop, child0-chain shadow walk and node / triangle buffers as compute.wgsl; they differ in the triangle
+// test (moller_trumbore<1>), plain mul / add where compute.wgsl writes fma, the sky colour on a miss, an 8-tap Poisson-disk
+// area light, their RNGs and the GI estimator.  Constant albedo (both files), WIDE64 records.
+__constant__ float c_poisson[8][2] = {{-0.7071f, 0.7071f}, {0.7071f, 0.7071f}, {0.7071f, -0.7071f}, {-0.7071f, -0.7071f},
+                                      {-0.3536f, 0.9239f}, {0.9239f, 0.3536f}, {0.3536f, -0.9239f}, {-0.9239f, -0.3536f}};   // web/shader.wgsl:27-36
+
+// web/shader.wgsl:240-270 = shader.wgsl:355-384
+template <bool COUNT>
+RT_DEV float direct_radiance_disk(const Scene& S, const Shade& sh, V3 hit_os, V3 n_os, V3 light_os, float radius, Work& W, RayCount& R) {
+  const V3 L = normalize3(light_os - hit_os);
+  const float diff = fmaxf(dot3(n_os, L), 0.0f);
+  if (diff <= 0.0f) return 0.0f;
+  uint32_t occ = 0;
+  const V3 perp1 = normalize3(cross3(n_os, L));
+  const V3 perp2 = cross3(L, perp1);
+  const uint32_t SOFT = (uint32_t)sh.soft_samples;
+  const V3 ro2 = hit_os + n_os * 0.001f;
+  for (uint32_t i = 0; i < SOFT; ++i) {
+    const float ox = c_poisson[i][0] * radius, oy = c_poisson[i][1] * radius;
+    const V3 samplePos = (light_os + perp1 * ox) + perp2 * oy;
+    const V3 d = samplePos - hit_os;
+    const V3 rd2 = normalize3(d);
+    const float sd = length3(d);
+    R.shadow += 1;
+    if (occluded_wide<COUNT, 1>(S, ro2, rd2, sd - 0.001f, W)) occ += 1;
+  }
+  const float shadowFactor = 1.0f - (float)occ / (float)SOFT;
+  return diff * shadowFactor;
+}
+
+RT_DEV bool is_safe_vec(V3 v) {   // shader.wgsl:170-172
+  return (length3(v) < 1e19f) && (fabsf(v.x) <= 1e30f) && (fabsf(v.y) <= 1e30f) && (fabsf(v.z) <= 1e30f);
+}
+
+// shader.wgsl:45-50,334-352 : HEMI_SAMPLES[idx] = (((idx % 8) * 2 + 1) / 16, ((idx / 8) * 2 + 1) / 16), exact in f32
+RT_DEV V3 sample_hemisphere_fixed(V3 n, uint32_t idx) {
+  const float sx = (float)((idx & 7u) * 2u + 1u) / 16.0f, sy = (float)((idx >> 3) * 2u + 1u) / 16.0f;
+  const float theta = sx * 6.28318530718f;
+  const float phi = rt_acos(sqrtf(sy));
+  float sinP, cosP, sinT, cosT;
+  rt_sincos(phi, &sinP, &cosP);
+  rt_sincos(theta, &sinT, &cosT);
+  const V3 up = (fabsf(n.y) < 0.999f) ? v3(0.0f, 1.0f, 0.0f) : v3(1.0f, 0.0f, 0.0f);
+  const V3 T = normalize3(cross3(up, n));
+  const V3 B = cross3(n, T);
+  return normalize3((T * (sinP * cosT) + n * cosP) + B * (sinP * sinT));
+}
+
+// web/shader.wgsl:369-433 (V = 1) ; shader.wgsl:387-447 (V = 2)
+template <bool COUNT, int V>
+RT_DEV PixelOut shade_frag(const Scene& S, const Shade& sh, const float* U, uint32_t gx, uint32_t gy, uint32_t w, uint32_t h,
+                           uint32_t miss_rgba, Work& W, RayCount& R) {
+  const PrimaryRay pr = primary_ray(U, gx, gy, w, h, V);
+  const V3 light_os = pr.light;
+  const float radius = U[7];
+  PixelOut out;
+  R.primary += 1;
+  const Hit hit0 = closest_wide<COUNT, 1>(S, pr.ro, pr.rd, pr.inv, 1e20f, W);
+  out.tri = hit0.tri; out.t = hit0.t; out.cost = hit0.steps;
+  if (hit0.t >= 1e19f) { out.rgba = miss_rgba; out.tri = 0xFFFFFFFFu; return out; }       // sky
+  const V3 hit_pos = pr.ro + pr.rd * hit0.t;
+  V3 n_os = hit_normal_plain(S, hit0);
+  const V3 albedo = v3(1.0f, 0.84f, 0.0f);
+  const uint32_t GI = (uint32_t)sh.gi_samples;
+  V3 col;
+  if (V == 1) {
+    const float directScalar = direct_radiance_disk<COUNT>(S, sh, hit_pos, n_os, light_os, radius, W, R);
+    const V3 Lo = albedo * directScalar;
+    V3 indirect = v3(0.0f, 0.0f, 0.0f);
+    const uint32_t NB = (uint32_t)sh.gi_bounces;
+    for (uint32_t i = 0; i < GI; ++i) {
+      V3 throughput = albedo;
+      V3 ro_b = hit_pos + n_os * 0.001f;
+      V3 n_b = n_os;
+      for (uint32_t b = 0; b < NB; ++b) {
+        const float rx = frag_rand2<1>((float)i, (float)b + 17.0f);
+        const float ry = frag_rand2<1>((float)i + 37.0f, (float)b);
+        const V3 dir = sample_hemisphere(n_b, rx, ry);          // :189-204, the statements of compute.wgsl:153-163
+        R.bounce += 1;
+        const Hit h1 = closest_wide<COUNT, 1>(S, ro_b, dir, rcp3(dir), 50.0f, W);
+        out.cost += h1.steps;
+        if (h1.t >= 50.0f) break;
+        const V3 p1 = ro_b + dir * h1.t;
+        const V3 nn1 = hit_normal_plain(S, h1);
+        const float dS = direct_radiance_disk<COUNT>(S, sh, p1, nn1, light_os, radius, W, R);
+        indirect = indirect + throughput * dS;
+        throughput = throughput * albedo;
+        ro_b = p1 + nn1 * 0.001f;
+        n_b = nn1;
+      }
+    }
+    indirect = indirect / (float)GI;
+    col = Lo + indirect;
+  } else {
+    if (!is_safe_vec(n_os)) n_os = v3(0.0f, 1.0f, 0.0f);
+    const float direct = direct_radiance_disk<COUNT>(S, sh, hit_pos, n_os, light_os, radius, W, R);
+    float indirect = 0.0f;
+    const float giProb = 0.9f;
+    for (uint32_t i = 0; i < GI; ++i) {
+      const float sx = pr.uvx + (float)i * 0.031f, sy = pr.uvy + (float)i * 0.047f;
+      if (frag_rand2<2>(sx, sy) > giProb) continue;
+      const V3 dir1 = sample_hemisphere_fixed(n_os, i);
+      const V3 ro1 = hit_pos + n_os * 0.001f;
+      R.bounce += 1;
+      const Hit h1 = closest_wide<COUNT, 1>(S, ro1, dir1, rcp3(dir1), 50.0f, W);
+      out.cost += h1.steps;
+      if (h1.t < 50.0f) {
+        const V3 p1 = ro1 + dir1 * h1.t;
+        V3 nn1 = hit_normal_plain(S, h1);
+        if (!is_safe_vec(nn1)) nn1 = v3(0.0f, 1.0f, 0.0f);
+        indirect = indirect + direct_radiance_disk<COUNT>(S, sh, p1, nn1, light_os, radius, W, R) / giProb;
+      }
+    }
+    indirect = indirect / (float)GI;
+    const float k = direct + indirect * 0.6f;
+    col = albedo * k;
+  }
   const float g = 1.0f / 2.2f;
   out.rgba = unorm8(rt_pow(col.x, g)) | (unorm8(rt_pow(col.y, g)) << 8) | (unorm8(rt_pow(col.z, g)) << 16) | 0xFF000000u;
   return out;
@@ -593,12 +735,12 @@ __global__ __launch_bounds__(TBLK) void k_cull(const RtRenderParams p) {
         const int tx0 = (int)(tx * 8u), ty0 = (int)local_to_global_row(p, ty * 8u);
         const bool tile_in = tx0 <= p.cull_x1 && tx0 + 7 >= p.cull_x0 && ty0 <= p.cull_y1 && ty0 + 7 >= p.cull_y0;
         if (tile_in) {
-          const PrimaryRay pr = primary_ray(p.U, x, y, p.width, p.height);
+          const PrimaryRay pr = primary_ray(p.U, x, y, p.width, p.height, p.frag);
           float tn, tf; slab(pr.ro, pr.inv, xyz(ra), xyz(rb), tn, tf);
           enters = box_hit(tn, tf, 1e20f);
         }
         if (!enters) {                                        // ray / box-test / pixel counts: k_stats_final
-          if (p.rgba8) reinterpret_cast<uint32_t*>(p.rgba8)[idx] = 0xFF000000u;
+          if (p.rgba8) reinterpret_cast<uint32_t*>(p.rgba8)[idx] = p.miss_rgba;
           if (p.hit_tri) p.hit_tri[idx] = 0xFFFFFFFFu;
           if (p.hit_t) p.hit_t[idx] = 1e20f;
         } else if (p.pix_class) {
@@ -716,8 +858,10 @@ extern "C" int rt_debug_timeline(unsigned long long* out, size_t n_words) {
 }
 #endif
 
-template <int LAYOUT, bool COUNT, bool TEX, bool PTSPLIT>
+enum { KIND_PIXEL = 0, KIND_PTSPLIT = 1, KIND_FRAG_WEB = 2, KIND_FRAG_ROOT = 3 };   // what a lane does with its pixel
+template <int LAYOUT, bool COUNT, bool TEX, int KIND>
 __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
+  constexpr bool PTSPLIT = KIND == KIND_PTSPLIT;
   extern __shared__ __align__(16) unsigned char smem[];
 #ifdef RT_TIMELINE
   const unsigned long long tl_start = wall_clock64();
@@ -774,6 +918,8 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
         const uint32_t y = local_to_global_row(p, lrow);
         PixelOut o;
         if constexpr (PTSPLIT) { o = shade_pt_primary<LAYOUT, COUNT, TEX>(S, sh, p.U, x, y, p.width, p.height, time_h, W, R, rec, rec_hit); rec.idx = idx; }
+        else if constexpr (KIND == KIND_FRAG_WEB) o = shade_frag<COUNT, 1>(S, sh, p.U, x, y, p.width, p.height, p.miss_rgba, W, R);
+        else if constexpr (KIND == KIND_FRAG_ROOT) o = shade_frag<COUNT, 2>(S, sh, p.U, x, y, p.width, p.height, p.miss_rgba, W, R);
         else o = shade_pixel<LAYOUT, COUNT, TEX>(S, sh, p.U, x, y, p.width, p.height, time_h, W, R);
         if (p.rgba8 && !rec_hit) reinterpret_cast<uint32_t*>(p.rgba8)[idx] = o.rgba;     // a PT hit pixel gets its colour in part 2
         if (p.hit_tri) p.hit_tri[idx] = o.tri;
@@ -938,14 +1084,16 @@ __global__ __launch_bounds__(TBLK) void k_deinterleave(const T* __restrict__ pac
 // late behind another one (measured: with a 4-blocks/CU grid and 3 resident, a quarter of the
 // waves started 400 us into a 650 us launch).
 uint32_t rt_render_grid(int n_cu) { return (uint32_t)n_cu * 8u; }   // upper bound (sizes the per-block stats slots: two launches with the PT split)
-static uint32_t resident_grid(int n_cu, int max_stack, bool tex) {
-  static int per_cu[2][33] = {};
-  int& slot = per_cu[tex ? 1 : 0][max_stack];
+static uint32_t resident_grid(int n_cu, int max_stack, bool tex, int frag = 0) {
+  static int per_cu[4][33] = {};
+  int& slot = per_cu[frag ? 1 + frag : (tex ? 1 : 0)][max_stack];
   if (slot == 0) {
     int nb = 0;
     const size_t lds = (size_t)max_stack * TBLK * 8;
-    const hipError_t e = tex ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_render<RT_LAYOUT_WIDE64, true, true, false>), TBLK, lds)
-                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_render<RT_LAYOUT_WIDE64, true, false, false>), TBLK, lds);
+    const hipError_t e = frag == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_render<RT_LAYOUT_WIDE64, true, false, KIND_FRAG_WEB>), TBLK, lds)
+                       : frag == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_render<RT_LAYOUT_WIDE64, true, false, KIND_FRAG_ROOT>), TBLK, lds)
+                       : tex ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_render<RT_LAYOUT_WIDE64, true, true, KIND_PIXEL>), TBLK, lds)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_render<RT_LAYOUT_WIDE64, true, false, KIND_PIXEL>), TBLK, lds);
     if (e != hipSuccess || nb < 1) nb = 2;
     slot = nb > 4 ? 4 : nb;
     if (const char* e = getenv("RTCORE_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= slot) slot = v; }
@@ -1014,10 +1162,10 @@ void rt_launch_render(const RtRenderParams& p_in, int layout, bool count_work, b
                       hipEvent_t ev1) {
   RtRenderParams p = p_in;
   const dim3 b(TBLK), gc(rt_cull_blocks(p.n_tiles));
-  p.render_blocks = resident_grid(n_cu, p.max_stack, p.tri_uv != nullptr);
+  p.render_blocks = resident_grid(n_cu, p.max_stack, p.tri_uv != nullptr, p.frag);
   hipLaunchKernelGGL(k_cull, gc, b, 0, s, p);
   hipLaunchKernelGGL(k_compact, gc, b, 0, s, p);
-  const dim3 g(resident_grid(n_cu, p.max_stack, p.tri_uv != nullptr));
+  const dim3 g(p.render_blocks);
   const size_t lds = (size_t)p.max_stack * TBLK * (sizeof(uint32_t) + sizeof(float));
   if (ev0) (void)hipEventRecord(ev0, s);
   const bool tex = p.tri_uv != nullptr, split = p.pt_cap != 0;
@@ -1027,12 +1175,20 @@ void rt_launch_render(const RtRenderParams& p_in, int layout, bool count_work, b
 #define RT_LAUNCH_RENDER(L, C, X)                                                              \
   do {                                                                                          \
     if (split) {                                                                                \
-      hipLaunchKernelGGL((k_render<L, C, X, true>), g, b, lds, s, p);                           \
+      hipLaunchKernelGGL((k_render<L, C, X, KIND_PTSPLIT>), g, b, lds, s, p);                   \
       hipLaunchKernelGGL((k_pt_samples<L, C, X>), g, b, lds, s, p2);                            \
       hipLaunchKernelGGL(k_pt_resolve, dim3((p.pt_cap + TBLK - 1) / TBLK, N_SHARD), b, 0, s, p); \
-    } else hipLaunchKernelGGL((k_render<L, C, X, false>), g, b, lds, s, p);                     \
+    } else hipLaunchKernelGGL((k_render<L, C, X, KIND_PIXEL>), g, b, lds, s, p);                \
   } while (0)
-  if (layout == RT_LAYOUT_WIDE64) {
+  if (p.frag) {   // older fragment shaders: WIDE64 records, constant albedo (rt_render_device rejects anything else)
+    if (p.frag == 1) {
+      if (count_work) hipLaunchKernelGGL((k_render<RT_LAYOUT_WIDE64, true, false, KIND_FRAG_WEB>), g, b, lds, s, p);
+      else hipLaunchKernelGGL((k_render<RT_LAYOUT_WIDE64, false, false, KIND_FRAG_WEB>), g, b, lds, s, p);
+    } else {
+      if (count_work) hipLaunchKernelGGL((k_render<RT_LAYOUT_WIDE64, true, false, KIND_FRAG_ROOT>), g, b, lds, s, p);
+      else hipLaunchKernelGGL((k_render<RT_LAYOUT_WIDE64, false, false, KIND_FRAG_ROOT>), g, b, lds, s, p);
+    }
+  } else if (layout == RT_LAYOUT_WIDE64) {
     if (count_work) { if (tex) RT_LAUNCH_RENDER(RT_LAYOUT_WIDE64, true, true); else RT_LAUNCH_RENDER(RT_LAYOUT_WIDE64, true, false); }
     else { if (tex) RT_LAUNCH_RENDER(RT_LAYOUT_WIDE64, false, true); else RT_LAUNCH_RENDER(RT_LAYOUT_WIDE64, false, false); }
   } else {

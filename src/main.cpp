@@ -7,7 +7,9 @@
 // and frame() :865-945 (uniforms, dispatch).
 //
 //   rt_host --obj web/plane.obj [--mtl-dir models] [--width 1920 --height 1080]
-//           [--mode primary|shadow|pt] [--spp 32] [--bounces 3] [--soft 4] [--stack 12]
+//           [--mode primary|shadow|pt|frag-web|frag-root] [--spp 32] [--bounces 3] [--soft 4] [--stack 12]
+//             (--mode sets the sample counts / stack depth its shader file is written with: give --spp etc. AFTER it;
+//              frag-web / frag-root = the older fragment shaders web/shader.wgsl / shader.wgsl, sky on a miss)
 //           [--layout wide64|aos32] [--cam x y z] [--yaw r] [--pitch r] [--frames n]
 //           [--save-bvh f] [--load-bvh f] [--out image.ppm] [--device 0] [--quad] [--v2]
 //           [--textured] [--texture slot=image.ppm ...]   materials from the MTL (Kd, map_Kd -> slot = material index
@@ -97,7 +99,11 @@ int main(int argc, char** argv) {
     else if (a == "--cam") { for (int k = 0; k < 3; ++k) cam.pos[k] = std::atof(next("--cam")); }
     else if (a == "--mode") {
       std::string m = next("--mode");
-      opts.mode = (m == "primary") ? RT_MODE_PRIMARY : (m == "shadow") ? RT_MODE_SHADOW : RT_MODE_PT;
+      const int layout = opts.layout;
+      const int mode = (m == "primary") ? RT_MODE_PRIMARY : (m == "shadow") ? RT_MODE_SHADOW : (m == "frag-web") ? RT_MODE_FRAG_WEB
+                     : (m == "frag-root") ? RT_MODE_FRAG_ROOT : (m == "pt") ? RT_MODE_PT : -1;
+      if (rt_render_opts_for_mode(&opts, mode) != RT_OK) { std::fprintf(stderr, "rt_host: --mode primary|shadow|pt|frag-web|frag-root\n"); return 2; }
+      opts.layout = layout;
     } else if (a == "--layout") {
       std::string m = next("--layout");
       opts.layout = (m == "aos32") ? RT_LAYOUT_AOS32 : RT_LAYOUT_WIDE64;
