@@ -705,11 +705,45 @@ constexpr int N_CLASS = 3;
 static int shard_stride_words() { return SHARD_STRIDE; }
 
 
-// Phase A1 — cull.  One lane per pixel of an 8x8 tile.  A primary ray that misses the root box
-// (compute.wgsl:275 on node 0) can never hit anything: its pixel is final here ((0,0,0,1),
-// compute.wgsl:365-367).  The ballots of the remaining lanes, split by last frame's cost class, are the tile's masks.
+// Phase A1 — cull.  A primary ray that misses the root box (compute.wgsl:275 on node 0) can never hit anything: its pixel
+// is final here (the miss colour, compute.wgsl:365-367).  Two levels, because one lane per pixel with a full ray set-up
+// (two normalisations, nine divisions) made this kernel 35 us at cfg 3, where nearly every ray enters the box:
+//   level 1, lane = tile: the rays through the tile's 4 corner pixels.  Rays from one origin that hit a convex box form a
+//     convex cone and a pixel's (un-normalised) direction is a convex combination of its tile's corner directions, so a
+//     tile whose 4 corner rays enter needs no per-pixel test.  (Calling a pixel "entering" is always safe: k_render tests
+//     the root box itself and writes the same miss.  Only "culled" must be certain, and that stays a per-pixel f32 test.)
+//   level 2, lane = one 8-pixel ROW of a tile (a wave covers 8 tiles): the ray test only in silhouette tiles; last
+//     frame's 8 cost classes of the row are one 8-byte load.  The row's 8-bit masks (entering pixels by class) are bytes
+//     of the tile's 64-bit masks in LDS — bit 8 * row + x, the order k_compact and k_render expect.
+RT_DEV void cull_write_miss(const RtRenderParams& p, size_t idx0, uint32_t bits) {
+  const bool vec = bits == 0xFFu && (p.width & 3u) == 0u;      // a whole row of a whole tile: 2 x 16-byte stores per output
+  if (p.rgba8) {
+    uint32_t* d = reinterpret_cast<uint32_t*>(p.rgba8) + idx0;
+    if (vec && (reinterpret_cast<uintptr_t>(p.rgba8) & 15u) == 0u) {
+      const uint4 v = make_uint4(p.miss_rgba, p.miss_rgba, p.miss_rgba, p.miss_rgba);
+      reinterpret_cast<uint4*>(d)[0] = v; reinterpret_cast<uint4*>(d)[1] = v;
+    } else for (int i = 0; i < 8; ++i) if ((bits >> i) & 1u) d[i] = p.miss_rgba;
+  }
+  if (p.hit_tri) {
+    uint32_t* d = p.hit_tri + idx0;
+    if (vec && (reinterpret_cast<uintptr_t>(p.hit_tri) & 15u) == 0u) {
+      const uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+      reinterpret_cast<uint4*>(d)[0] = v; reinterpret_cast<uint4*>(d)[1] = v;
+    } else for (int i = 0; i < 8; ++i) if ((bits >> i) & 1u) d[i] = 0xFFFFFFFFu;
+  }
+  if (p.hit_t) {
+    float* d = p.hit_t + idx0;
+    if (vec && (reinterpret_cast<uintptr_t>(p.hit_t) & 15u) == 0u) {
+      const float4 v = make_float4(1e20f, 1e20f, 1e20f, 1e20f);
+      reinterpret_cast<float4*>(d)[0] = v; reinterpret_cast<float4*>(d)[1] = v;
+    } else for (int i = 0; i < 8; ++i) if ((bits >> i) & 1u) d[i] = 1e20f;
+  }
+}
+
 __global__ __launch_bounds__(TBLK) void k_cull(const RtRenderParams p) {
-  __shared__ uint32_t s_cnt[N_CLASS][CULL_TPB];
+  __shared__ uint8_t s_corner[4][CULL_TPB];
+  __shared__ uint32_t s_txy[CULL_TPB];
+  __shared__ unsigned long long s_m[N_CLASS][CULL_TPB];      // the block's tile masks; byte r of a mask comes from the lane of tile row r
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float4 ra = reinterpret_cast<const float4*>(p.nodes)[0], rb = reinterpret_cast<const float4*>(p.nodes)[1];
   if (blockIdx.x == 0)   // phase-B queue heads start at zero (k_render runs two launches later)
@@ -717,47 +751,75 @@ __global__ __launch_bounds__(TBLK) void k_cull(const RtRenderParams p) {
       p.shard_heads[i] = 0u;
       if (p.pt_cap) { p.pt_heads[i] = 0u; if (i < (uint32_t)N_SHARD) p.pt_count[i] = 0u; }
     }
-#pragma unroll 1
-  for (int r = 0; r < CULL_TPB / (TBLK / 64); ++r) {
-    const int k = r * (TBLK / 64) + w;                       // the 4 waves of a block work on 4 adjacent tiles
-    const uint32_t tile = blockIdx.x * CULL_TPB + (uint32_t)k;
-    unsigned long long m[N_CLASS] = {0ull, 0ull, 0ull};
+  {   // level 1: wave w traces corner w of the block's 64 tiles (0: x0 y0, 1: x7 y0, 2: x0 y7, 3: x7 y7)
+    const uint32_t tile = blockIdx.x * CULL_TPB + (uint32_t)lane;
+    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;   // once per tile: <= 8192 tiles per axis (resolution <= 65536)
+    if (w == 0) s_txy[lane] = tx | (ty << 16);
+    uint8_t state = 0;                                      // 0 = outside the root box's screen rectangle (or no tile), 1 = corner ray enters, 2 = corner ray misses
     if (tile < p.n_tiles) {
-      const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
-      const uint32_t x = tx * 8u + (uint32_t)(lane & 7), lrow = ty * 8u + (uint32_t)(lane >> 3);
-      const uint32_t y = local_to_global_row(p, lrow);
-      bool enters = false;
-      uint32_t cls = 0;
-      if (x < p.width && lrow < p.local_rows && y < p.height) {
-        const uint32_t idx = lrow * p.width + x;
-        // tiles wholly outside the conservative screen rectangle of the root box need no ray (wave-uniform test:
-        // a tile's 8 rows are contiguous in the global image because stripes are multiples of 8 rows)
-        const int tx0 = (int)(tx * 8u), ty0 = (int)local_to_global_row(p, ty * 8u);
-        const bool tile_in = tx0 <= p.cull_x1 && tx0 + 7 >= p.cull_x0 && ty0 <= p.cull_y1 && ty0 + 7 >= p.cull_y0;
-        if (tile_in) {
-          const PrimaryRay pr = primary_ray(p.U, x, y, p.width, p.height, p.frag);
-          float tn, tf; slab(pr.ro, pr.inv, xyz(ra), xyz(rb), tn, tf);
-          enters = box_hit(tn, tf, 1e20f);
-        }
-        if (!enters) {                                        // ray / box-test / pixel counts: k_stats_final
-          if (p.rgba8) reinterpret_cast<uint32_t*>(p.rgba8)[idx] = p.miss_rgba;
-          if (p.hit_tri) p.hit_tri[idx] = 0xFFFFFFFFu;
-          if (p.hit_t) p.hit_t[idx] = 1e20f;
-        } else if (p.pix_class) {
-          cls = p.pix_class[idx];                             // last frame's hint; anything else than 1 / 2 counts as 0
-        }
+      const int tx0 = (int)(tx * 8u), ty0 = (int)local_to_global_row(p, ty * 8u);   // a tile's 8 rows are contiguous in the image: stripes are multiples of 8 rows
+      const bool tile_in = tx0 <= p.cull_x1 && tx0 + 7 >= p.cull_x0 && ty0 <= p.cull_y1 && ty0 + 7 >= p.cull_y0;
+      if (tile_in) {
+        const PrimaryRay pr = primary_ray(p.U, (uint32_t)tx0 + ((w & 1) ? 7u : 0u), (uint32_t)ty0 + ((w & 2) ? 7u : 0u), p.width, p.height, p.frag);
+        float tn, tf; slab(pr.ro, pr.inv, xyz(ra), xyz(rb), tn, tf);
+        state = box_hit(tn, tf, 1e20f) ? 1 : 2;
       }
-      if (p.class_promote && __ballot(enters && cls == 2u) != 0ull && cls == 1u) cls = 2u;   // a hot pixel makes its tile's normal pixels hot
-      m[2] = __ballot(enters && cls == 2u);
-      m[1] = __ballot(enters && cls == 1u);
-      m[0] = __ballot(enters && cls != 1u && cls != 2u);
-      if (lane < N_CLASS) p.masks[(size_t)tile * N_CLASS + lane] = (lane == 0) ? m[0] : (lane == 1) ? m[1] : m[2];
     }
-    if (lane < N_CLASS) s_cnt[lane][k] = (uint32_t)__popcll((lane == 0) ? m[0] : (lane == 1) ? m[1] : m[2]);
+    s_corner[w][lane] = state;
   }
   __syncthreads();
-  if (w < N_CLASS) {
-    const uint32_t tot = wave_sum_u32(s_cnt[w][lane]);
+  uint8_t* sm8 = reinterpret_cast<uint8_t*>(&s_m[0][0]);
+  const int row = lane & 7;
+#pragma unroll 1
+  for (int r = 0; r < CULL_TPB / (8 * (TBLK / 64)); ++r) {
+    const int k = (r * (TBLK / 64) + w) * 8 + (lane >> 3);     // tile of the block this lane's row belongs to
+    const uint32_t tile = blockIdx.x * CULL_TPB + (uint32_t)k;
+    uint32_t e = 0, c1 = 0, c2 = 0;                             // 8-bit row masks: entering pixels; of them, last frame's class 1 / class 2
+    if (tile < p.n_tiles) {
+      const uint32_t txy = s_txy[k], x0 = (txy & 0xFFFFu) * 8u, lrow = (txy >> 16) * 8u + (uint32_t)row;
+      const uint32_t y = local_to_global_row(p, lrow);
+      uint32_t vm = 0;                                          // pixels of the row that exist
+      if (lrow < p.local_rows && y < p.height) vm = (p.width - x0 >= 8u) ? 0xFFu : ((1u << (p.width - x0)) - 1u);
+      const uint32_t cs = (uint32_t)s_corner[0][k] | ((uint32_t)s_corner[1][k] << 8) | ((uint32_t)s_corner[2][k] << 16) | ((uint32_t)s_corner[3][k] << 24);
+      if (cs == 0x01010101u) e = vm;
+      else if ((cs & 0xFFu) != 0u && vm) {                      // silhouette tile: the reference's own test, per pixel
+#pragma unroll 1
+        for (uint32_t i = 0; i < 8u; ++i) {
+          if (!((vm >> i) & 1u)) continue;
+          const PrimaryRay pr = primary_ray(p.U, x0 + i, y, p.width, p.height, p.frag);
+          float tn, tf; slab(pr.ro, pr.inv, xyz(ra), xyz(rb), tn, tf);
+          if (box_hit(tn, tf, 1e20f)) e |= 1u << i;
+        }
+      }
+      const size_t idx0 = (size_t)lrow * p.width + x0;
+      if (vm & ~e) cull_write_miss(p, idx0, vm & ~e);            // ray / box-test / pixel counts of these: k_stats_final
+      if (e && p.pix_class) {                                    // last frame's hints; anything else than 1 / 2 counts as 0
+        unsigned long long cls = 0ull;
+        if ((p.width & 7u) == 0u) cls = *reinterpret_cast<const unsigned long long*>(p.pix_class + idx0);
+        else for (uint32_t i = 0; i < 8u; ++i) if ((vm >> i) & 1u) cls |= (unsigned long long)p.pix_class[idx0 + i] << (8u * i);
+#pragma unroll
+        for (uint32_t i = 0; i < 8u; ++i) {
+          const uint32_t b = (uint32_t)(cls >> (8u * i)) & 0xFFu;
+          c1 |= (b == 1u ? 1u : 0u) << i;
+          c2 |= (b == 2u ? 1u : 0u) << i;
+        }
+        c1 &= e; c2 &= e;
+      }
+    }
+    if (p.class_promote) {                                       // a hot pixel makes its tile's normal pixels hot
+      const unsigned long long hot = __ballot(c2 != 0u);
+      if ((hot >> (lane & 56)) & 0xFFull) { c2 |= c1; c1 = 0u; }
+    }
+    sm8[((size_t)(0 * CULL_TPB + k)) * 8 + row] = (uint8_t)(e & ~(c1 | c2));
+    sm8[((size_t)(1 * CULL_TPB + k)) * 8 + row] = (uint8_t)c1;
+    sm8[((size_t)(2 * CULL_TPB + k)) * 8 + row] = (uint8_t)c2;
+  }
+  __syncthreads();
+  if (w < N_CLASS) {                                             // lane = tile: masks out, per-class totals of the block
+    const uint32_t tile = blockIdx.x * CULL_TPB + (uint32_t)lane;
+    const unsigned long long m = s_m[w][lane];
+    if (tile < p.n_tiles) p.masks[(size_t)tile * N_CLASS + w] = m;
+    const uint32_t tot = wave_sum_u32((uint32_t)__popcll(m));
     if (lane == 0) p.block_total[(size_t)blockIdx.x * N_CLASS + w] = tot;
   }
 }
@@ -768,9 +830,17 @@ __global__ __launch_bounds__(TBLK) void k_cull(const RtRenderParams p) {
 __global__ __launch_bounds__(TBLK) void k_compact(const RtRenderParams p) {
   __shared__ uint32_t s_red[TBLK / 64][2 * N_CLASS];
   __shared__ uint32_t s_pref[N_CLASS][CULL_TPB];
+  __shared__ uint32_t s_txy[CULL_TPB];
+  __shared__ unsigned long long s_mask[N_CLASS][CULL_TPB];   // the block's masks, read from HBM once (the rounds below took one dependent load each)
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint32_t n_blocks = gridDim.x, me = blockIdx.x;
   uint32_t all[N_CLASS] = {0, 0, 0}, mine[N_CLASS] = {0, 0, 0};     // class totals of the frame / of the blocks before me
+  unsigned long long my_mask = 0ull;
+  {
+    const uint32_t tile = me * CULL_TPB + (uint32_t)lane;
+    if (w < N_CLASS && tile < p.n_tiles) my_mask = p.masks[(size_t)tile * N_CLASS + w];
+    if (w == N_CLASS) s_txy[lane] = (tile % p.tiles_x) | ((tile / p.tiles_x) << 16);   // the idle wave: tile coordinates, once per tile
+  }
   for (uint32_t i = threadIdx.x; i < n_blocks; i += TBLK) {
 #pragma unroll
     for (int c = 0; c < N_CLASS; ++c) {
@@ -785,8 +855,7 @@ __global__ __launch_bounds__(TBLK) void k_compact(const RtRenderParams p) {
     if (lane == 0) { s_red[w][c] = a; s_red[w][N_CLASS + c] = m; }
   }
   if (w < N_CLASS) {                                          // wave c scans the block's 64 tile counts of class c
-    const uint32_t tile = me * CULL_TPB + (uint32_t)lane;
-    const uint32_t c = (tile < p.n_tiles) ? (uint32_t)__popcll(p.masks[(size_t)tile * N_CLASS + w]) : 0u;
+    const uint32_t c = (uint32_t)__popcll(my_mask);
     uint32_t inc = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -794,6 +863,7 @@ __global__ __launch_bounds__(TBLK) void k_compact(const RtRenderParams p) {
       if (lane >= o) inc += t;
     }
     s_pref[w][lane] = inc - c;
+    s_mask[w][lane] = my_mask;
   }
   __syncthreads();
   uint32_t tot[2 * N_CLASS];
@@ -832,11 +902,11 @@ __global__ __launch_bounds__(TBLK) void k_compact(const RtRenderParams p) {
     const int k = r * (TBLK / 64) + w;
     const uint32_t tile = me * CULL_TPB + (uint32_t)k;
     if (tile >= p.n_tiles) break;
-    const uint32_t tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+    const uint32_t txy = s_txy[k], tx = txy & 0xFFFFu, ty = txy >> 16;
     const uint32_t x = tx * 8u + (uint32_t)(lane & 7), lrow = ty * 8u + (uint32_t)(lane >> 3);
 #pragma unroll
     for (int c = 0; c < N_CLASS; ++c) {
-      const unsigned long long m = p.masks[(size_t)tile * N_CLASS + c];
+      const unsigned long long m = s_mask[c][k];
       if ((m >> lane) & 1ull) p.list[base[c] + s_pref[c][k] + (uint32_t)__popcll(m & lt)] = lrow * p.width + x;
     }
   }
