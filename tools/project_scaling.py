@@ -42,18 +42,32 @@ def run(world, rank, fif, n=200):
         f.step(U, want_stats=False)
     f.finish()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        f.step(U, want_stats=False)
-    f.finish()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n * 1e3
+    # timed in 4 chunks, median chunk reported: a one-off host stall (~35 ms, seen once per process about a second after
+    # start, whatever was running: hipEvent times of the frames' kernels are unaffected) would otherwise count as 0.17 ms/frame
+    ctx.profile_begin()
+    chunks = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        for _ in range(n // 4):
+            f.step(U, want_stats=False)
+        f.finish()
+        torch.cuda.synchronize()
+        chunks.append((time.perf_counter() - t0) / (n // 4) * 1e3)
+    dt = sorted(chunks)[1]
+    fr, tr, _ = ctx.profile_end()
+    if "--verbose" in sys.argv:
+        print(f"   world {world} rank {rank}: {dt:.4f} ms/frame; frame kernels {fr:.4f} ms, k_render {tr:.4f} ms (hipEvents, overlapped frames inflate both); "
+              f"packed @ {[hex(t.data_ptr()) for t in f.packed_ring]}", flush=True)
+    return dt
 
 
+order = (lambda w: range(w)) if "--reverse" not in sys.argv else (lambda w: reversed(range(w)))
 t1 = run(1, 0, 1)
 print(f"N=1 (one frame in flight, as bench.py): {t1:.4f} ms/frame", flush=True)
-for world in (2, 4, 8):
-    ts = [run(world, r, 3) for r in range(world)]
+worlds = (2, 4, 8) if "--worlds" not in sys.argv else tuple(int(v) for v in sys.argv[sys.argv.index("--worlds") + 1].split(","))
+for world in worlds:
+    ts = {r: run(world, r, 3) for r in order(world)}
+    ts = [ts[r] for r in range(world)]
     print(f"N={world}: per-rank ms/frame {[round(t, 4) for t in ts]} -> slowest {max(ts):.4f}, projected speed-up {t1 / max(ts):.2f}x "
           f"({t1 / max(ts) / world * 100:.0f} % of linear)", flush=True)
 dist.destroy_process_group()
