@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librtcore.so")
+LIB_PATH = os.environ.get("RTCORE_LIBRARY") or os.path.join(_HERE, "lib", "librtcore.so")   # RTCORE_LIBRARY: another build of the same ABI (A/B experiments)
 
 RT_OK, RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_IO, RT_ERR_LIMIT, RT_ERR_INTERNAL = 0, -1, -2, -3, -4, -5, -6
 MODE_PRIMARY, MODE_SHADOW, MODE_PT = 0, 1, 2

@@ -391,9 +391,16 @@ __global__ __launch_bounds__(BLK) void k_refit(const float* __restrict__ pos, co
                                                int leaf_shift, bool v2) {
   __shared__ float s_box[2 * BLK][6];      // [0, BLK): this block's leaves, [BLK, 2 BLK): internal nodes with index in the block's range
   __shared__ uint32_t s_visit[BLK];        // arrival counters of the block-local internal nodes
+  __shared__ int s_child[BLK][2];          // links of the internal nodes with index in the block's range, read once, coalesced:
+  __shared__ int s_parent[BLK];            // the local climb then has no dependent global load per level
   s_visit[threadIdx.x] = 0u;
-  __syncthreads();
   const uint32_t j = blockIdx.x * BLK + threadIdx.x;
+  if (j + 1 < n_tri) {
+    const int2 c = reinterpret_cast<const int2*>(child)[j];
+    s_child[threadIdx.x][0] = c.x; s_child[threadIdx.x][1] = c.y;
+    s_parent[threadIdx.x] = parent[j];
+  }
+  __syncthreads();
   if (j >= n_tri) return;
   const int first_leaf = (int)n_tri - 1;   // leaf j is node (T-1)+j, one triangle, start = j
   const uint32_t ti = order[j];
@@ -434,6 +441,11 @@ __global__ __launch_bounds__(BLK) void k_refit(const float* __restrict__ pos, co
     const bool local = (pe & PARENT_LOCAL) != 0;
     const int par = pe & PARENT_MASK;
     uint32_t arrived;
+    int gc0 = 0, gc1 = 0, gpe = -1;
+    if (!local) {                                      // the global path's links do not depend on who arrives second: issue the loads
+      const int2 c = reinterpret_cast<const int2*>(child)[par];   // before the wait + atomic instead of two more round trips after them
+      gc0 = c.x; gc1 = c.y; gpe = parent[par];
+    }
     if (local) {
       float* sb = s_box[cur_slot];
       sb[0] = mn.x; sb[1] = mn.y; sb[2] = mn.z; sb[3] = mx.x; sb[4] = mx.y; sb[5] = mx.z;
@@ -445,7 +457,8 @@ __global__ __launch_bounds__(BLK) void k_refit(const float* __restrict__ pos, co
       arrived = atomicAdd(&visit[par], 1u);
     }
     if (arrived == 0) break;                           // the sibling's thread will finish this node
-    const int c0 = child[2 * (size_t)par + 0], c1 = child[2 * (size_t)par + 1];
+    const int c0 = local ? s_child[par & (BLK - 1)][0] : gc0;
+    const int c1 = local ? s_child[par & (BLK - 1)][1] : gc1;
     const int sib = (c0 == cur) ? c1 : c0;
     V3 smn, smx;
     if (local) {
@@ -469,7 +482,7 @@ __global__ __launch_bounds__(BLK) void k_refit(const float* __restrict__ pos, co
     }
     mn = v3(fminf(mn.x, smn.x), fminf(mn.y, smn.y), fminf(mn.z, smn.z));
     mx = v3(fmaxf(mx.x, smx.x), fmaxf(mx.y, smx.y), fmaxf(mx.z, smx.z));
-    pe = parent[par];
+    pe = local ? s_parent[par & (BLK - 1)] : gpe;
     store_node<FENCED>(nodes, par, mn, enc_index(v2, (uint32_t)c0), mx, enc_index(v2, (uint32_t)c1),   // v1: indices as f32 values (F11)
                        pe >= 0 && !(pe & PARENT_LOCAL));
     cur = par;
