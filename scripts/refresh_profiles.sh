@@ -1,0 +1,23 @@
+#!/bin/bash
+# Everything profiles/r1 holds, measured in ONE gpurun call (one box: boxes differ by a few % in k_render time).
+#   gpurun --timeout 1200 -- 'scripts/refresh_profiles.sh'   then, here:   python scripts/collect_profiles.py
+set -e
+R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/refresh"; rm -rf "$O"; mkdir -p "$O"
+cd "$R"
+echo "[1] gpu tests"; timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > "$O/gpu_tests.log" 2>&1; tail -1 "$O/gpu_tests.log"
+echo "[2] default bench line"; timeout -k 10 300 python bench.py > "$O/bench_n1.json" 2> "$O/bench_n1.err"
+echo "[3] kernel trace"; scripts/kernel_stats.sh gpurun_out/refresh/ks > "$O/ks.txt" 2>&1; cd "$R"
+echo "[4] pmc passes"; scripts/pmc_passes.sh "$O/pmc" --steps 5 --warmup 3 > "$O/pmc.txt" 2>&1; cd "$R"
+python3 scripts/pmc_summary.py "$O/pmc" "$O/traffic_all.json" > "$O/pmc_summary.txt"
+echo "[5] variants"
+b() { name=$1; shift; timeout -k 10 400 python bench.py --no-cpu-baseline "$@" > "$O/bench_$name.json" 2> "$O/bench_$name.err"; echo "  $name done"; }
+b notexture --no-texture
+b primary --mode primary
+b aos32 --layout aos32
+b pt16 --mode pt --spp 16 --steps 10
+b s70k_1080p --scene s70k --width 1920 --height 1080 --mode primary
+RTCORE_COHERENT_SCHEDULING=0 b unhinted
+RTCORE_PT_SPLIT=0 b pt16_unsplit --mode pt --spp 16 --steps 10
+echo "[6] cfg 5"; timeout -k 10 500 python bench.py --no-cpu-baseline --scene lattice76 --width 7680 --height 4320 --steps 10 > "$O/bench_cfg5_100Mtri_8k.json" 2> "$O/bench_cfg5.err"
+echo "[7] frag"; b frag_root --mode frag-root --steps 10; b frag_web --mode frag-web --steps 5
+echo done
