@@ -208,7 +208,8 @@ int rt_render(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* opts,
 /* Same, outputs in caller-provided DEVICE memory of this context's GPU, asynchronous on
  * the context stream unless stats != NULL.  With striping the outputs are PACKED: local
  * row = (stripe / stripe_world) * stripe_rows + row_in_stripe (rt_packed_rows gives the
- * row count). */
+ * row count).  The three pointers must be 4-byte aligned (pixels are stored as 32-bit words; RT_ERR_INVALID otherwise);
+ * 16-byte alignment lets whole culled rows go out as 16-byte stores. */
 int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* opts,
                      void* d_rgba8, void* d_hit_tri, void* d_hit_t, rt_render_stats* out);
 uint32_t rt_packed_rows(uint32_t height, int32_t stripe_rows, int32_t stripe_rank, int32_t stripe_world);

@@ -745,6 +745,8 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
   if (!uniforms) return ctx->fail(RT_ERR_INVALID, "uniforms are NULL");
   int rc = check_opts(ctx, opts);
   if (rc != RT_OK) return rc;
+  if (((reinterpret_cast<uintptr_t>(d_rgba8) | reinterpret_cast<uintptr_t>(d_hit_tri) | reinterpret_cast<uintptr_t>(d_hit_t)) & 3u) != 0u)
+    return ctx->fail(RT_ERR_INVALID, "output pointers must be 4-byte aligned");
   const float fw = uniforms[36], fh = uniforms[37];
   if (!(fw >= 1.0f) || !(fh >= 1.0f) || fw > 65536.0f || fh > 65536.0f) return ctx->fail(RT_ERR_INVALID, "resolution out of range");
   DeviceGuard g(ctx->device);

@@ -90,3 +90,28 @@ def test_two_frames_in_flight_without_collective(gpu_ctx, rt, plane_mesh):
 def test_profile_end_needs_begin(gpu_ctx, rt):
     with pytest.raises(rt.RtError):
         gpu_ctx.profile_end()
+
+
+def test_caller_buffers_with_4_byte_alignment(gpu_ctx, rt, plane_mesh):
+    """rt_render_device takes any 4-byte-aligned device pointers: k_cull writes whole culled rows with 16-byte stores only
+    where the pointer allows it.  Camera A (almost every pixel culled) into buffers offset by 4, 8 and 12 bytes."""
+    import torch
+    gpu_ctx.set_mesh(plane_mesh)
+    gpu_ctx.build_lbvh()
+    w, h = 200, 120
+    opts = rt.render_opts(mode=rt.MODE_SHADOW)
+    for view in (dict(cam_pos=(0.0, 0.0, 5.0)), dict(PLANE_VIEW)):
+        U = rt.make_uniforms(w, h, **view)
+        ref, _ = gpu_ctx.render(U, opts)
+        for off in (1, 2, 3):
+            bufs = [torch.full((w * h + 8,), 0x5A5A5A5A, dtype=torch.int32, device="cuda:0") for _ in range(3)]
+            ptr = [b.data_ptr() + 4 * off for b in bufs]
+            gpu_ctx.render_device(U, opts, d_rgba8=ptr[0], d_hit_tri=ptr[1], d_hit_t=ptr[2])
+            got = [b.cpu().numpy() for b in bufs]
+            for g in got:                                   # nothing outside [off, off + w h) was touched
+                assert np.all(g[:off] == 0x5A5A5A5A) and np.all(g[off + w * h:] == 0x5A5A5A5A)
+            assert np.array_equal(got[0][off:off + w * h].view(np.uint8).reshape(h, w, 4), ref["rgba8"])
+            assert np.array_equal(got[1][off:off + w * h].view(np.uint32).reshape(h, w), ref["hit_tri"])
+            assert np.array_equal(got[2][off:off + w * h].view(np.float32).reshape(h, w), ref["hit_t"])
+    with pytest.raises(rt.RtError):
+        gpu_ctx.render_device(U, opts, d_rgba8=bufs[0].data_ptr() + 2)
