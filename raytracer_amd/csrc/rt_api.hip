@@ -801,6 +801,7 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
   HIPCHK(ctx->r_stats[slot].ensure(8 + 32 + (size_t)rt_render_grid(ctx->n_cu) * 8 + 3 * (size_t)p.n_tiles));
   HIPCHK(ctx->r_list[slot].ensure((size_t)p.local_rows * p.width));
   p.shard_stride = rt_shard_stride();
+  p.blocks_per_cu_cap = overlap ? 2u : 0u;
   p.shard_group = 8;
   // PT split (sample-parallel GI) wherever its fixed-size term registers suffice; RTCORE_PT_SPLIT=0 keeps one lane per pixel
   {

@@ -88,6 +88,7 @@ struct RtRenderParams {
   uint32_t  pt_cap;
   float*    pt_terms;              // [gi_samples][gi_bounces * 3 + 1][N_SHARD * pt_cap]: bounce terms + their count per (sample, record)
   uint32_t  render_blocks;         // grid of k_render (number of class_hist rows in use)
+  uint32_t  blocks_per_cu_cap;     // 0 = everything that is resident; frames that overlap others take 2 blocks per CU each
   unsigned long long* stats;       // [8]: rays_primary, rays_shadow, rays_bounce, box, tri, hitupd, pixels, drops
   unsigned long long* stats_partial;   // [rt_render_grid()*8] per-block partials of phase B
 };
