@@ -797,8 +797,8 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
   } else {
     JOIN_FRAMES();
   }
-  HIPCHK(ctx->r_tile_counter[slot].ensure(2 * (size_t)rt_shard_words() + 32 + 64 + 3 * (size_t)cull_blocks));
-  HIPCHK(ctx->r_stats[slot].ensure(8 + 32 + (size_t)rt_render_grid(ctx->n_cu) * 8 + 3 * (size_t)p.n_tiles));
+  HIPCHK(ctx->r_tile_counter[slot].ensure(2 * (size_t)rt_shard_words() + 32 + 64 + (size_t)rt_n_class() * cull_blocks));
+  HIPCHK(ctx->r_stats[slot].ensure(8 + 32 + (size_t)rt_render_grid(ctx->n_cu) * 8 + (size_t)rt_n_class() * p.n_tiles));
   HIPCHK(ctx->r_list[slot].ensure((size_t)p.local_rows * p.width));
   p.shard_stride = rt_shard_stride();
   p.blocks_per_cu_cap = overlap ? 2u : 0u;
@@ -865,6 +865,25 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
     if (const char* e = std::getenv("RTCORE_TILE_PROMOTE")) p.class_promote = (uint32_t)std::atoi(e);
     p.class_hot_pct = moved ? 10u : 20u;    // unpromoted, static view: 20 / 30 / 40 / 50 % -> k_render 0.394 / 0.415 / 0.394 / 0.451 ms (cfg 3), 3.20 / 3.21 / 3.23 / 3.27 ms (cfg 5)
     if (const char* e = std::getenv("RTCORE_HOT_PCT")) p.class_hot_pct = (uint32_t)std::atoll(e);
+    {   // quantile bands of the non-cheap pixels, hottest last: with 5 classes the top 50 / 25 / 10 %
+      const uint32_t n_hot = rt_n_class() - 2u;
+      static const uint32_t shares[7][6] = {{0}, {20}, {35, 20}, {45, 25, 12}, {60, 40, 20, 8}, {65, 45, 30, 15, 6}, {70, 50, 35, 22, 12, 5}};
+      for (uint32_t k = 0; k < 6; ++k) p.class_share[k] = k < n_hot ? shares[n_hot][k] : 0u;
+      // Measured with 4 classes (k_render, one box, 3-class build beside it): cfg 3 0.388 vs 0.426 ms, cfg 5 3.08 vs 3.17,
+      // S70k 4K 0.375 vs 0.381, 8-copy lattice 0.620 vs 0.625, S70k 1080p 0.222 vs 0.215 (the one loss).  The landscape is
+      // jumpy: {40,15} is as good on cfg 3 but 12 % worse on S70k 1080p, {25,8} and {50,20} lose most of the gain.
+      // PT part 1 keeps ONE hot class: the order of its records is also the order k_pt_samples walks them in, and finer
+      // classes there cost 4 % (4.03 vs 3.86 ms).
+      if (n_hot == 1 || std::getenv("RTCORE_HOT_PCT") || opts->mode == RT_MODE_PT) {
+        p.class_share[0] = p.class_hot_pct;
+        for (uint32_t k = 1; k < 6; ++k) p.class_share[k] = 0u;      // share 0: the class stays empty
+      }
+      else if (moved) for (uint32_t k = 0; k < n_hot; ++k) p.class_share[k] = (p.class_share[k] + 1u) / 2u;
+      if (const char* e = std::getenv("RTCORE_CLASS_SHARES")) {   // e.g. "50,25,10"
+        uint32_t k = 0;
+        for (const char* q = e; *q && k < n_hot; ++k) { p.class_share[k] = (uint32_t)std::strtoul(q, const_cast<char**>(&q), 10); if (*q == ',') ++q; }
+      }
+    }
     if (const char* e = std::getenv("RTCORE_T1")) p.class_t1 = (uint32_t)std::atoll(e);
     if (const char* e = std::getenv("RTCORE_T2")) p.class_t2 = (uint32_t)std::atoll(e);
   }

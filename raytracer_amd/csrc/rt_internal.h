@@ -74,12 +74,13 @@ struct RtRenderParams {
   uint32_t* list;                  // [local_rows*width] compacted pixel ids (phase A -> phase B): hot class first
   uint32_t* list_count;            // written by k_compact
   // Frame-coherent scheduling hints (never results): cost class of every pixel as measured by the previous frame
-  // (0 = cheap or unknown, 1 = normal, 2 = hot), read by k_cull, rewritten by k_render.  NULL = no hints.
+  // (0 = cheap or unknown, 1 = normal, 2 .. N-1 = hotter and hotter), read by k_cull, rewritten by k_render.  NULL = no hints.
   uint8_t*  pix_class;             // [local_rows*width]
   uint32_t  class_promote;         // k_cull: a tile with a hot pixel traces all its non-cheap pixels with the hot class
   uint32_t  class_t1, class_t2;    // traversal steps: class = (steps >= t1) + (steps >= t2); t2 == 0: adaptive, see class_hist
   uint32_t* class_hist;            // [64] histogram of (steps - t1) / 4 over last frame's pixels with steps >= t1 (k_render adds, k_compact reads + clears)
   uint32_t  class_hot_pct;         // adaptive t2: the hot class is about this share of last frame's non-cheap pixels (k_compact -> list_count[2])
+  uint32_t  class_share[6];        // classes 2 .. N-1: class c holds about the top class_share[c-2] % of last frame's non-cheap pixels (descending; [0] = class_hot_pct)
   // PT split (sample-parallel GI, rt_trace.hip): phase 1 (k_render) leaves one record per hit pixel in the sub-list of the queue
   // shard its chunk came from; phase 2 (k_pt_samples) traces ONE GI sample of 64 records per wave item, phase 3 (k_pt_resolve) sums.  pt_cap == 0: no split.
   float4*   pt_recs;               // [N_SHARD][pt_cap][3]: {hit_pos, d0} {n_os, bits(pixel idx)} {albedo, bits(pixelIndex)}
@@ -130,6 +131,7 @@ void rt_launch_pack_impl(const RtBvhDev& bvh, uint32_t* d_root_ref, uint32_t* d_
 // ---------------------------------------------------------------- traversal (rt_trace.hip)
 uint32_t rt_render_grid(int n_cu);   // blocks of the persistent phase-B grid
 uint32_t rt_cull_blocks(uint32_t n_tiles);
+uint32_t rt_n_class();            // cost classes of the pixel list (rt_trace.hip N_CLASS)
 uint32_t rt_shard_words();
 uint32_t rt_pt_capacity(uint32_t n_pixels, uint32_t shard_group);   // records per PT sub-list that can never overflow
 uint32_t rt_shard_stride();

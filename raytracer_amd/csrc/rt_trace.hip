@@ -702,7 +702,11 @@ __global__ void k_stats_final(const RtRenderParams p, uint32_t n_blocks, uint32_
 constexpr int CULL_TPB = 64;          // tiles per k_cull / k_compact block: 16 rounds x 4 waves
 constexpr int N_SHARD = 64;           // phase-B queue shards, one 128-byte line of queue state each
 constexpr int SHARD_STRIDE = 32;      // uint32 words between shard heads: one 128-byte line each
-constexpr int N_CLASS = 3;
+#ifndef RT_N_CLASS
+#define RT_N_CLASS 4
+#endif
+constexpr int N_CLASS = RT_N_CLASS;   // cost classes of the pixel list: 0 cheap / unknown, 1 normal, 2 .. N-1 quantile bands of the non-cheap pixels
+static_assert(N_CLASS >= 3 && N_CLASS <= 8, "class_share[] holds N_CLASS - 2 <= 6 entries");
 static int shard_stride_words() { return SHARD_STRIDE; }
 
 
@@ -775,7 +779,9 @@ __global__ __launch_bounds__(TBLK) void k_cull(const RtRenderParams p) {
   for (int r = 0; r < CULL_TPB / (8 * (TBLK / 64)); ++r) {
     const int k = (r * (TBLK / 64) + w) * 8 + (lane >> 3);     // tile of the block this lane's row belongs to
     const uint32_t tile = blockIdx.x * CULL_TPB + (uint32_t)k;
-    uint32_t e = 0, c1 = 0, c2 = 0;                             // 8-bit row masks: entering pixels; of them, last frame's class 1 / class 2
+    uint32_t e = 0, cm[N_CLASS];                                // 8-bit row masks: entering pixels; of them, last frame's class c (cm[0] is filled last)
+#pragma unroll
+    for (int c = 0; c < N_CLASS; ++c) cm[c] = 0u;
     if (tile < p.n_tiles) {
       const uint32_t txy = s_txy[k], x0 = (txy & 0xFFFFu) * 8u, lrow = (txy >> 16) * 8u + (uint32_t)row;
       const uint32_t y = local_to_global_row(p, lrow);
@@ -801,27 +807,42 @@ __global__ __launch_bounds__(TBLK) void k_cull(const RtRenderParams p) {
 #pragma unroll
         for (uint32_t i = 0; i < 8u; ++i) {
           const uint32_t b = (uint32_t)(cls >> (8u * i)) & 0xFFu;
-          c1 |= (b == 1u ? 1u : 0u) << i;
-          c2 |= (b == 2u ? 1u : 0u) << i;
+#pragma unroll
+          for (int c = 1; c < N_CLASS; ++c) cm[c] |= (b == (uint32_t)c ? 1u : 0u) << i;
         }
-        c1 &= e; c2 &= e;
+#pragma unroll
+        for (int c = 1; c < N_CLASS; ++c) cm[c] &= e;
       }
     }
-    if (p.class_promote) {                                       // a hot pixel makes its tile's normal pixels hot
-      const unsigned long long hot = __ballot(c2 != 0u);
-      if ((hot >> (lane & 56)) & 0xFFull) { c2 |= c1; c1 = 0u; }
+    if (p.class_promote) {                                       // the hottest pixel of a tile gives its class to the tile's non-cheap pixels
+      unsigned long long has[N_CLASS];
+#pragma unroll
+      for (int c = 2; c < N_CLASS; ++c) has[c] = __ballot(cm[c] != 0u);
+      int top = 0;
+#pragma unroll
+      for (int c = 2; c < N_CLASS; ++c) if ((has[c] >> (lane & 56)) & 0xFFull) top = c;
+      if (top) {
+        uint32_t all = 0u;
+#pragma unroll
+        for (int c = 1; c < N_CLASS; ++c) { all |= cm[c]; cm[c] = 0u; }
+#pragma unroll
+        for (int c = 2; c < N_CLASS; ++c) if (c == top) cm[c] = all;
+      }
     }
-    sm8[((size_t)(0 * CULL_TPB + k)) * 8 + row] = (uint8_t)(e & ~(c1 | c2));
-    sm8[((size_t)(1 * CULL_TPB + k)) * 8 + row] = (uint8_t)c1;
-    sm8[((size_t)(2 * CULL_TPB + k)) * 8 + row] = (uint8_t)c2;
+    uint32_t any = 0u;
+#pragma unroll
+    for (int c = 1; c < N_CLASS; ++c) any |= cm[c];
+    cm[0] = e & ~any;
+#pragma unroll
+    for (int c = 0; c < N_CLASS; ++c) sm8[((size_t)(c * CULL_TPB + k)) * 8 + row] = (uint8_t)cm[c];
   }
   __syncthreads();
-  if (w < N_CLASS) {                                             // lane = tile: masks out, per-class totals of the block
+  for (int c = w; c < N_CLASS; c += TBLK / 64) {                 // lane = tile: masks out, per-class totals of the block
     const uint32_t tile = blockIdx.x * CULL_TPB + (uint32_t)lane;
-    const unsigned long long m = s_m[w][lane];
-    if (tile < p.n_tiles) p.masks[(size_t)tile * N_CLASS + w] = m;
+    const unsigned long long m = s_m[c][lane];
+    if (tile < p.n_tiles) p.masks[(size_t)tile * N_CLASS + c] = m;
     const uint32_t tot = wave_sum_u32((uint32_t)__popcll(m));
-    if (lane == 0) p.block_total[(size_t)blockIdx.x * N_CLASS + w] = tot;
+    if (lane == 0) p.block_total[(size_t)blockIdx.x * N_CLASS + c] = tot;
   }
 }
 
@@ -836,11 +857,16 @@ __global__ __launch_bounds__(TBLK) void k_compact(const RtRenderParams p) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint32_t n_blocks = gridDim.x, me = blockIdx.x;
   uint32_t all[N_CLASS] = {0, 0, 0}, mine[N_CLASS] = {0, 0, 0};     // class totals of the frame / of the blocks before me
-  unsigned long long my_mask = 0ull;
+  constexpr int CPW = (N_CLASS + TBLK / 64 - 1) / (TBLK / 64);     // classes per wave: wave w scans classes w, w + 4
+  unsigned long long my_mask[CPW];
   {
     const uint32_t tile = me * CULL_TPB + (uint32_t)lane;
-    if (w < N_CLASS && tile < p.n_tiles) my_mask = p.masks[(size_t)tile * N_CLASS + w];
-    if (w == N_CLASS) s_txy[lane] = (tile % p.tiles_x) | ((tile / p.tiles_x) << 16);   // the idle wave: tile coordinates, once per tile
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+      const int c = w + i * (TBLK / 64);
+      my_mask[i] = (c < N_CLASS && tile < p.n_tiles) ? p.masks[(size_t)tile * N_CLASS + c] : 0ull;
+    }
+    if (w == TBLK / 64 - 1) s_txy[lane] = (tile % p.tiles_x) | ((tile / p.tiles_x) << 16);   // tile coordinates, once per tile
   }
   for (uint32_t i = threadIdx.x; i < n_blocks; i += TBLK) {
 #pragma unroll
@@ -855,16 +881,19 @@ __global__ __launch_bounds__(TBLK) void k_compact(const RtRenderParams p) {
     const uint32_t a = wave_sum_u32(all[c]), m = wave_sum_u32(mine[c]);
     if (lane == 0) { s_red[w][c] = a; s_red[w][N_CLASS + c] = m; }
   }
-  if (w < N_CLASS) {                                          // wave c scans the block's 64 tile counts of class c
-    const uint32_t c = (uint32_t)__popcll(my_mask);
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {                             // a wave scans the block's 64 tile counts of its classes
+    const int cl = w + i * (TBLK / 64);
+    if (cl >= N_CLASS) break;
+    const uint32_t c = (uint32_t)__popcll(my_mask[i]);
     uint32_t inc = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const uint32_t t = (uint32_t)__shfl_up((int)inc, o);
       if (lane >= o) inc += t;
     }
-    s_pref[w][lane] = inc - c;
-    s_mask[w][lane] = my_mask;
+    s_pref[cl][lane] = inc - c;
+    s_mask[cl][lane] = my_mask[i];
   }
   __syncthreads();
   uint32_t tot[2 * N_CLASS];
@@ -874,15 +903,17 @@ __global__ __launch_bounds__(TBLK) void k_compact(const RtRenderParams p) {
 #pragma unroll
     for (int i = 0; i < TBLK / 64; ++i) tot[k] += s_red[i][k];
   }
-  // list order: hot (2), normal (1), cheap / unknown (0)
-  uint32_t base[N_CLASS];
-  base[2] = tot[N_CLASS + 2];
-  base[1] = tot[2] + tot[N_CLASS + 1];
-  base[0] = tot[2] + tot[1] + tot[N_CLASS + 0];
-  if (me == 0 && threadIdx.x == 0) { p.list_count[0] = tot[0] + tot[1] + tot[2]; p.list_count[1] = tot[2]; }   // all, hot
+  // list order: hottest class first, cheap / unknown (0) last
+  uint32_t base[N_CLASS], above = 0u;
+#pragma unroll
+  for (int c = N_CLASS - 1; c >= 0; --c) { base[c] = above + tot[N_CLASS + c]; above += tot[c]; }
+  if (me == 0 && threadIdx.x == 0) { p.list_count[0] = above; p.list_count[1] = tot[N_CLASS - 1]; }   // all entries, hottest class
   if (me == 0 && w == TBLK / 64 - 1 && p.pix_class) {   // hot threshold of THIS frame from last frame's step histogram
-    uint32_t t2 = p.class_t2;
-    if (t2 == 0u) {                                       // lane b owns bin b: steps in [t1 + 4 b, t1 + 4 b + 4), last bin open
+    // thresholds of classes 2 .. N-1 (list_count[2 ..]): fixed t2 -> one hot class; adaptive -> quantile bands
+    uint32_t thr[N_CLASS];
+#pragma unroll
+    for (int c = 2; c < N_CLASS; ++c) thr[c] = (c == 2) ? p.class_t2 : 0xFFFFFFFFu;
+    if (p.class_t2 == 0u) {                               // lane b owns bin b: steps in [t1 + 4 b, t1 + 4 b + 4), last bin open
       const unsigned long long mine = p.class_hist[lane];
       p.class_hist[lane] = 0u;                            // this frame's k_render (next launch) accumulates afresh
       unsigned long long suffix = mine;                   // pixels in bins >= lane
@@ -891,11 +922,17 @@ __global__ __launch_bounds__(TBLK) void k_compact(const RtRenderParams p) {
         if (lane + o < 64) suffix += t;
       }
       const unsigned long long total = __shfl(suffix, 0);
-      // first bin whose suffix fits into the hot share; no data -> no hot class
-      const unsigned long long ok = __ballot(total > 0ull && suffix * 100ull <= total * p.class_hot_pct);
-      t2 = ok ? p.class_t1 + 4u * (uint32_t)(__ffsll((long long)ok) - 1) : 0xFFFFFFFFu;
+#pragma unroll
+      for (int c = 2; c < N_CLASS; ++c) {                 // first bin whose suffix fits into the class's share; no data -> no such class
+        const unsigned long long ok = __ballot(total > 0ull && suffix * 100ull <= total * p.class_share[c - 2]);
+        thr[c] = ok ? p.class_t1 + 4u * (uint32_t)(__ffsll((long long)ok) - 1) : 0xFFFFFFFFu;
+      }
     }
-    if (lane == 0) p.list_count[2] = max(t2, p.class_t1 + 1u);
+    if (lane == 0) {
+      uint32_t floor_t = p.class_t1 + 1u;                 // thresholds ascend with the class
+#pragma unroll
+      for (int c = 2; c < N_CLASS; ++c) { thr[c] = max(thr[c], floor_t); floor_t = thr[c]; p.list_count[c] = thr[c]; }
+    }
   }
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll 1
@@ -957,7 +994,9 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
   RayCount R; R.primary = R.shadow = R.bounce = 0;
   uint32_t pixels = 0;
   const uint32_t n_list = *p.list_count;                 // written by k_compact (previous launch on this stream)
-  const uint32_t class_t2 = p.pix_class ? p.list_count[2] : 0xFFFFFFFFu;
+  uint32_t class_thr[N_CLASS];                           // class_thr[c], c >= 2: steps from which a pixel is of class c (k_compact)
+#pragma unroll
+  for (int c = 2; c < N_CLASS; ++c) class_thr[c] = p.pix_class ? p.list_count[c] : 0xFFFFFFFFu;
   __shared__ uint32_t s_hist[64];                        // this block's step histogram of non-cheap pixels (next frame's threshold)
   if (threadIdx.x < 64) s_hist[threadIdx.x] = 0u;
   __syncthreads();
@@ -996,7 +1035,10 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
         if (p.hit_tri) p.hit_tri[idx] = o.tri;
         if (p.hit_t) p.hit_t[idx] = o.t;
         if (p.pix_class) {
-          p.pix_class[idx] = (uint8_t)((o.cost >= p.class_t1 ? 1u : 0u) + (o.cost >= class_t2 ? 1u : 0u));
+          uint32_t cls = o.cost >= p.class_t1 ? 1u : 0u;
+#pragma unroll
+          for (int c = 2; c < N_CLASS; ++c) cls += o.cost >= class_thr[c] ? 1u : 0u;
+          p.pix_class[idx] = (uint8_t)cls;
           if (o.cost >= p.class_t1) atomicAdd(&s_hist[min((o.cost - p.class_t1) >> 2, 63u)], 1u);
         }
         pixels += 1;
@@ -1172,6 +1214,7 @@ static uint32_t resident_grid(int n_cu, int max_stack, bool tex, int frag = 0) {
   return (uint32_t)n_cu * (uint32_t)slot;
 }
 uint32_t rt_cull_blocks(uint32_t n_tiles) { return (n_tiles + CULL_TPB - 1) / CULL_TPB; }
+uint32_t rt_n_class() { return (uint32_t)N_CLASS; }
 uint32_t rt_shard_words() { return N_SHARD * (uint32_t)shard_stride_words(); }
 uint32_t rt_shard_stride() { return (uint32_t)shard_stride_words(); }
 // a shard owns at most ceil(n_chunks / (N_SHARD * group)) groups of `group` chunks of 64 pixels
