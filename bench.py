@@ -65,6 +65,9 @@ def main():
                     help="asynchronous frames in flight per GPU (rtcore.h rt_set_frames_in_flight). auto = 1 on one GPU, so that every "
                          "k_render launch runs alone and its duration is the kernel's own (roofline), 3 with N > 1, where a rank's "
                          "share of the frame is small and mostly tail (3 frame streams + the context stream = the 4 hardware queues)")
+    ap.add_argument("--exchange", default="root", choices=["root", "all"],
+                    help="N > 1: where the frame's stripes are gathered — root = rank 0 only (the viewer's rank: grouped send/recv, each "
+                         "byte crosses one xGMI link once), all = every rank (all_gather, N times the traffic)")
     ap.add_argument("--no-fif2", action="store_true", help="skip the extra two-frames-in-flight loop at N = 1")
     ap.add_argument("--no-texture", action="store_true",
                     help="shade with the reference's constant albedo (compute.wgsl:372) instead of the materials + textures of cfg 3")
@@ -141,7 +144,7 @@ def main():
     shade = dict(gi_samples=shade.gi_samples, gi_bounces=shade.gi_bounces, soft_samples=shade.soft_samples, max_stack=shade.max_stack)
     base = rt.render_opts(mode=mode, layout=layout, flags=tflag, **shade)
     fif = (1 if world == 1 else 3) if args.frames_in_flight == "auto" else int(args.frames_in_flight)
-    frame = rdist.ShardedFrame(rdist.GpuBackend(ctx, device, frames_in_flight=fif), W, H, rank, world, base)
+    frame = rdist.ShardedFrame(rdist.GpuBackend(ctx, device, frames_in_flight=fif), W, H, rank, world, base, exchange=args.exchange)
 
     # one counted launch (untimed): rays + work counters of this rank's share of the frame
     copts = rt.render_opts(mode=mode, layout=layout, flags=rt.FLAG_COUNT_WORK | tflag, **shade,
@@ -221,7 +224,8 @@ def main():
                                    f"layout {args.layout}, node records {'v2' if encoding == rt.NODES_V2 else 'v1'}, "
                                    + ("textured shading: 3 materials, map_Kd 2048^2 + 1024^2 closed-form RGB8, nearest texel" if textured
                                       else "constant albedo (compute.wgsl:372)"),
-                       "mode": args.mode, "rays_per_frame": int(total_rays), "frames_in_flight": fif, "stripes": "16-row round-robin" if world > 1 else "none"},
+                       "mode": args.mode, "rays_per_frame": int(total_rays), "frames_in_flight": fif, "stripes": "16-row round-robin" if world > 1 else "none",
+                       "exchange": ("gather to rank 0" if args.exchange == "root" else "all_gather") if world > 1 else "none"},
             "lbvh_build_ms": {k: round(float(v), 4) for k, v in build.items() if k.startswith("ms_")},
             "lbvh_build_roofline_frac": round(build["algorithmic_bytes"] / (build["ms_total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
             "bvh_broadcast_ms": round(bcast_ms, 3),

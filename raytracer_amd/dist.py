@@ -2,7 +2,9 @@
 the two exchange steps the path really has —
   * BVH replication: built once on rank 0, the three flat buffers are broadcast over xGMI;
   * framebuffer gather: each rank renders its 16-row stripes (stripe s -> rank s % world) into
-    a PACKED buffer; all_gather of the equal-sized packed buffers + one de-interleave kernel.
+    a PACKED buffer; the equal-sized packed buffers are gathered — to rank 0 only (exchange="root": the viewer's rank,
+    grouped send/recv, every byte crosses one xGMI link once, 1/world of an all-gather's traffic) or to every rank
+    (exchange="all": all_gather) — and de-interleaved by one kernel wherever they arrive.
 Pixels are independent: there is no collective inside the traversal itself.
 
 torch is plumbing only (device buffers + collectives); compute is behind the C ABI.  The
@@ -45,13 +47,14 @@ class GpuBackend:
         """want_stats=True synchronises the context stream (stats are read back); False is fully asynchronous."""
         return self.ctx.render_device(U, opts, d_rgba8=packed.data_ptr(), want_stats=want_stats)
 
-    def gather(self, gathered, packed, keep_latest):
-        """all-gather of a finished frame's stripes on the context stream: the stream first waits for that frame
+    def gather(self, gathered, packed, keep_latest, root_only=False):
+        """Gather of a finished frame's stripes on the context stream: the stream first waits for that frame
         (all asynchronous frames issued so far, except the keep_latest most recent ones), then torch queues the
-        collective behind it (on this stream, or on its own communication stream ordered against it)."""
+        collective behind it (on this stream, or on its own communication stream ordered against it).
+        root_only: `gathered` is None on every rank but 0."""
         self.ctx.frames_join(int(keep_latest))
         with torch.cuda.stream(self.ext):
-            dist.all_gather_into_tensor(gathered, packed)
+            gather_stripes(gathered, packed, root_only)
 
     def deinterleave(self, gathered, image, width, height, world, rpr):
         self.ctx.deinterleave_device(gathered.data_ptr(), image.data_ptr(), width, height, 4, STRIPE_ROWS, world, rpr)
@@ -59,6 +62,16 @@ class GpuBackend:
     def finish(self):
         self.ctx.synchronize()
         torch.cuda.current_stream(self.device).synchronize()
+
+
+def gather_stripes(gathered, packed, root_only):
+    """The frame's one exchange step.  gathered: [world * rows_per_rank, width] (rank-major), or None off the root."""
+    if not root_only:
+        dist.all_gather_into_tensor(gathered, packed)
+    elif dist.get_rank() == 0:
+        dist.gather(packed, list(gathered.view(dist.get_world_size(), *packed.shape).unbind(0)), dst=0)
+    else:
+        dist.gather(packed, None, dst=0)
 
 
 def replicate_bvh(ctx, rank, world, device):
@@ -105,9 +118,14 @@ class ShardedFrame:
 
     DEPTH = 2      # ring of packed / gathered buffers and frames kept un-gathered (more with GpuBackend(frames_in_flight > 2))
 
-    def __init__(self, backend, width, height, rank, world, base_opts=None, force_collective=False):
-        """force_collective: run the gather + de-interleave leg even at world == 1 (tests the stream plumbing on one GPU)."""
+    def __init__(self, backend, width, height, rank, world, base_opts=None, force_collective=False, exchange="all"):
+        """force_collective: run the gather + de-interleave leg even at world == 1 (tests the stream plumbing on one GPU).
+        exchange: "all" = every rank ends up with the frame (all_gather); "root" = only rank 0 does (self.image is None elsewhere)."""
+        if exchange not in ("all", "root"):
+            raise ValueError("exchange must be 'all' or 'root'")
         self.b, self.w, self.h, self.rank, self.world = backend, width, height, rank, world
+        self.root_only = exchange == "root"
+        self.has_frame = rank == 0 or not self.root_only
         self.collective = world > 1 or force_collective
         self.rpr = rows_per_rank(height, world) if world > 1 else height
         o = base_opts or render_opts()
@@ -117,19 +135,21 @@ class ShardedFrame:
         # one output buffer per frame that can be in flight (also without a collective), at least two
         depth = max(self.DEPTH, getattr(backend, "fif", self.DEPTH))
         self.packed_ring = [backend.alloc(self.rpr, width) for _ in range(depth)]
-        self.gathered_ring = [backend.alloc(self.rpr * world, width) for _ in range(depth)] if self.collective else None
+        self.gathered_ring = ([backend.alloc(self.rpr * world, width) if self.has_frame else None for _ in range(depth)]
+                              if self.collective else None)
         self.packed = self.packed_ring[0]
-        self.image = backend.alloc(height, width) if self.collective else self.packed
+        self.image = (backend.alloc(height, width) if self.has_frame else None) if self.collective else self.packed
         self.n_steps = 0
         self.pending = []              # ring slots of the frames rendered (or rendering) but not yet gathered, oldest first
 
     def _exchange(self, slot, keep_latest):
         packed, gathered = self.packed_ring[slot], self.gathered_ring[slot]
         if hasattr(self.b, "gather"):
-            self.b.gather(gathered, packed, keep_latest)
+            self.b.gather(gathered, packed, keep_latest, self.root_only)
         else:
-            dist.all_gather_into_tensor(gathered, packed)
-        self.b.deinterleave(gathered, self.image, self.w, self.h, self.world, self.rpr)
+            gather_stripes(gathered, packed, self.root_only)
+        if self.has_frame:
+            self.b.deinterleave(gathered, self.image, self.w, self.h, self.world, self.rpr)
 
     def step(self, U, want_stats=True):
         """Render my stripes, gather all stripes, de-interleave.  Returns this rank's render stats (or None).

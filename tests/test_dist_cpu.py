@@ -117,6 +117,18 @@ def _worker(rank, world, port, q):
                 ok = ok and np.array_equal(frame.image.numpy(), refs[k - 1])
         frame.finish()
         ok = ok and np.array_equal(frame.image.numpy(), refs[-1]) and not np.array_equal(refs[-1], refs[-2])
+        # exchange="root": the same loop, the frame arrives on rank 0 only (grouped send / recv instead of the all-gather)
+        rframe = rdist.ShardedFrame(OracleBackend(oracle, mine), w, h, rank, world, rt.render_opts(mode=rt.MODE_SHADOW), exchange="root")
+        ok = ok and ((rframe.image is None) == (rank != 0))
+        for k, cam in enumerate(cams):
+            Uk = rt.make_uniforms(w, h, cam_pos=cam)
+            Uk[20:36] = np.eye(4, dtype=np.float32).reshape(-1)
+            rframe.step(Uk, want_stats=False)
+            if k >= 1 and rank == 0:
+                ok = ok and np.array_equal(rframe.image.numpy(), refs[k - 1])
+        rframe.finish()
+        if rank == 0:
+            ok = ok and np.array_equal(rframe.image.numpy(), refs[-1])
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

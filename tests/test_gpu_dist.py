@@ -29,8 +29,9 @@ def nccl_world1():
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("exchange", ["all", "root"])
 @pytest.mark.parametrize("fif", [1, 2, 4])
-def test_async_frames_with_forced_collective(gpu_ctx, rt, plane_mesh, nccl_world1, fif):
+def test_async_frames_with_forced_collective(gpu_ctx, rt, plane_mesh, nccl_world1, fif, exchange):
     import torch
 
     from raytracer_amd import dist as rdist
@@ -39,7 +40,8 @@ def test_async_frames_with_forced_collective(gpu_ctx, rt, plane_mesh, nccl_world
     w, h = 320, 200
     opts = rt.render_opts(mode=rt.MODE_SHADOW)
     dev = torch.device("cuda:0")
-    frame = rdist.ShardedFrame(rdist.GpuBackend(gpu_ctx, dev, frames_in_flight=fif), w, h, 0, 1, opts, force_collective=True)
+    frame = rdist.ShardedFrame(rdist.GpuBackend(gpu_ctx, dev, frames_in_flight=fif), w, h, 0, 1, opts, force_collective=True,
+                               exchange=exchange)
     views = [dict(PLANE_VIEW), dict(PLANE_VIEW, cam_pos=(0.1, 0.0, 1.2)), dict(PLANE_VIEW, rot_deg=(-70.0, 10.0, 0.0))]
     gpu_ctx.profile_begin()
     for k in range(9):                      # queued back to back: render k+1 must not overwrite stripes still being gathered
