@@ -66,7 +66,7 @@ t1 = run(1, 0, 1)
 print(f"N=1 (one frame in flight, as bench.py): {t1:.4f} ms/frame", flush=True)
 worlds = (2, 4, 8) if "--worlds" not in sys.argv else tuple(int(v) for v in sys.argv[sys.argv.index("--worlds") + 1].split(","))
 for world in worlds:
-    ts = {r: run(world, r, 3) for r in order(world)}
+    ts = {r: run(world, r, int(os.environ.get("PROJ_FIF", "3"))) for r in order(world)}
     ts = [ts[r] for r in range(world)]
     print(f"N={world}: per-rank ms/frame {[round(t, 4) for t in ts]} -> slowest {max(ts):.4f}, projected speed-up {t1 / max(ts):.2f}x "
           f"({t1 / max(ts) / world * 100:.0f} % of linear)", flush=True)
