@@ -16,4 +16,5 @@ run() {
 run sq "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "$@" &&
 run tcc "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE" "$@" &&
 run fetch "FETCH_SIZE" "$@" &&
-run write "WRITE_SIZE" "$@"
+run write "WRITE_SIZE" "$@" &&
+run lanes "SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES" "$@"   # lane utilisation = THREAD_CYCLES_VALU / (64 * ACTIVE_INST_VALU)
