@@ -4,6 +4,8 @@
 //   1: 1 x dwordx4 per lane (quarter of the record)
 //   2: quad-cooperative: 4 lanes fetch one record with one dwordx4 each; 4 instructions cover the wave's 64 records
 //   3: 2 x dwordx4 per lane (half record)
+//   4: 3 x dwordx4 + 1 x dwordx2 per lane (the 56 useful bytes of a two-child record)
+//   5: 3 x dwordx4 per lane (48 bytes)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -20,6 +22,8 @@ __global__ __launch_bounds__(256) void k(const float4* __restrict__ tab, uint32_
     if (V == 0) { const float4* p = tab + 4 * (size_t)cur; a = p[0]; b = p[1]; c = p[2]; d = p[3]; }
     else if (V == 1) { const float4* p = tab + 4 * (size_t)cur; a = p[0]; b = c = d = a; }
     else if (V == 3) { const float4* p = tab + 4 * (size_t)cur; a = p[0]; b = p[1]; c = a; d = b; }
+    else if (V == 4) { const float4* p = tab + 4 * (size_t)cur; a = p[0]; b = p[1]; c = p[2]; const float2 e = *reinterpret_cast<const float2*>(p + 3); d = make_float4(e.x, e.y, e.x, e.y); }
+    else if (V == 5) { const float4* p = tab + 4 * (size_t)cur; a = p[0]; b = p[1]; c = p[2]; d = a; }
     else {
       float4 r[4];
 #pragma unroll
@@ -41,13 +45,14 @@ int main() {
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0)); ncu = prop.multiProcessorCount;
   const int steps = 400;
   for (size_t mb : {1ul, 16ul, 84ul, 512ul}) {
+    if (getenv("UBENCH_MB") && (size_t)atoi(getenv("UBENCH_MB")) != mb) continue;
     const uint32_t n_rec = (uint32_t)(mb * 1024 * 1024 / 64);
     std::vector<float4> h((size_t)n_rec * 4);
     for (size_t i = 0; i < h.size(); ++i) { uint32_t x = (uint32_t)i * 2246822519u + 12345u; x ^= x >> 15; x *= 2654435761u; h[i] = make_float4(1e-9f, 1e-9f, 1e-9f, __builtin_bit_cast(float, x & 0x3fffffffu)); }
     float4* d; float* o; CK(hipMalloc(&d, h.size() * sizeof(float4))); CK(hipMalloc(&o, (size_t)ncu * 8 * 256 * 4));
     CK(hipMemcpy(d, h.data(), h.size() * sizeof(float4), hipMemcpyHostToDevice));
-    for (int bpc : {1, 3, 8}) {
-      for (int v = 0; v < 4; ++v) {
+    for (int bpc : {3}) {
+      for (int v = 0; v < 6; ++v) {
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         auto launch = [&]() {
           dim3 g(ncu * bpc), b(256);
@@ -55,6 +60,8 @@ int main() {
           if (v == 1) hipLaunchKernelGGL(k<1>, g, b, 0, 0, d, n_rec, steps, o);
           if (v == 2) hipLaunchKernelGGL(k<2>, g, b, 0, 0, d, n_rec, steps, o);
           if (v == 3) hipLaunchKernelGGL(k<3>, g, b, 0, 0, d, n_rec, steps, o);
+          if (v == 4) hipLaunchKernelGGL(k<4>, g, b, 0, 0, d, n_rec, steps, o);
+          if (v == 5) hipLaunchKernelGGL(k<5>, g, b, 0, 0, d, n_rec, steps, o);
         };
         launch(); CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
