@@ -6,6 +6,7 @@
 //   3: 2 x dwordx4 per lane (half record)
 //   4: 3 x dwordx4 + 1 x dwordx2 per lane (the 56 useful bytes of a two-child record)
 //   5: 3 x dwordx4 per lane (48 bytes)
+//   6 / 7: as 0, but every 4th / 2nd step goes to the OTHER 64-byte half of the same 128-byte line (a parent and its near child laid out as a pair)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -19,7 +20,7 @@ __global__ __launch_bounds__(256) void k(const float4* __restrict__ tab, uint32_
   float acc = 0.f;
   for (int s = 0; s < steps; ++s) {
     float4 a, b, c, d;
-    if (V == 0) { const float4* p = tab + 4 * (size_t)cur; a = p[0]; b = p[1]; c = p[2]; d = p[3]; }
+    if (V == 0 || V == 6 || V == 7) { const float4* p = tab + 4 * (size_t)cur; a = p[0]; b = p[1]; c = p[2]; d = p[3]; }
     else if (V == 1) { const float4* p = tab + 4 * (size_t)cur; a = p[0]; b = c = d = a; }
     else if (V == 3) { const float4* p = tab + 4 * (size_t)cur; a = p[0]; b = p[1]; c = a; d = b; }
     else if (V == 4) { const float4* p = tab + 4 * (size_t)cur; a = p[0]; b = p[1]; c = p[2]; const float2 e = *reinterpret_cast<const float2*>(p + 3); d = make_float4(e.x, e.y, e.x, e.y); }
@@ -35,7 +36,10 @@ __global__ __launch_bounds__(256) void k(const float4* __restrict__ tab, uint32_
       a = r[0]; b = r[1]; c = r[2]; d = r[3];
     }
     acc += a.x + b.y + c.z + d.w;
-    cur = (__float_as_uint(a.w) ^ (uint32_t)s * 0x9E3779B9u ^ cur * 747796405u) % n_rec;   // data-dependent next record
+    const uint32_t nxt = (__float_as_uint(a.w) ^ (uint32_t)s * 0x9E3779B9u ^ cur * 747796405u);
+    if (V == 6 && ((nxt >> 20) & 3u) == 0u) cur = cur ^ 1u;
+    else if (V == 7 && ((nxt >> 20) & 1u) == 0u) cur = cur ^ 1u;
+    else cur = nxt % n_rec;   // data-dependent next record
   }
   out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
@@ -52,7 +56,7 @@ int main() {
     float4* d; float* o; CK(hipMalloc(&d, h.size() * sizeof(float4))); CK(hipMalloc(&o, (size_t)ncu * 8 * 256 * 4));
     CK(hipMemcpy(d, h.data(), h.size() * sizeof(float4), hipMemcpyHostToDevice));
     for (int bpc : {3}) {
-      for (int v = 0; v < 6; ++v) {
+      for (int v : {0, 6, 7}) {
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         auto launch = [&]() {
           dim3 g(ncu * bpc), b(256);
@@ -62,6 +66,8 @@ int main() {
           if (v == 3) hipLaunchKernelGGL(k<3>, g, b, 0, 0, d, n_rec, steps, o);
           if (v == 4) hipLaunchKernelGGL(k<4>, g, b, 0, 0, d, n_rec, steps, o);
           if (v == 5) hipLaunchKernelGGL(k<5>, g, b, 0, 0, d, n_rec, steps, o);
+          if (v == 6) hipLaunchKernelGGL(k<6>, g, b, 0, 0, d, n_rec, steps, o);
+          if (v == 7) hipLaunchKernelGGL(k<7>, g, b, 0, 0, d, n_rec, steps, o);
         };
         launch(); CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
