@@ -148,8 +148,12 @@ int rt_get_triangles(rt_ctx* ctx, float* tri_pos /* [12*T] */, float* tri_nor /*
 int rt_set_bvh(rt_ctx* ctx, const float* nodes, uint32_t n_nodes,
                const float* tri_pos, const float* tri_nor, uint32_t n_tri);
 
-/* BVH cache file (what web/bvh-buffer.bin was meant to be):
- * header-less little-endian f32: nodes[8N] then tri_pos[12T] then tri_nor[12T]; N = 2T-1. */
+/* BVH cache file (what web/bvh-buffer.bin was meant to be): little-endian f32
+ * nodes[8N] then tri_pos[12T] then tri_nor[12T].  A v1 tree with N = 2T-1 (every LBVH build, the reference's builder at
+ * leaf size 1) is written header-less, so the file is the raw dump the reference's bindings 4/5 take.  Any other tree
+ * (multi-triangle leaves as flattenForSSBO writes them, script.js:546-559; v2 records) gets a 16-byte trailer
+ * {u32 magic "RTBV", n_nodes, n_tri, encoding}; rt_load_bvh reads both forms, and a trailer's encoding overrides (and
+ * becomes) the context's rt_set_node_encoding setting. */
 int rt_save_bvh(rt_ctx* ctx, const char* path);
 int rt_load_bvh(rt_ctx* ctx, const char* path);
 

@@ -176,7 +176,7 @@ int finish_bvh(rt_ctx* ctx, bool packed_by_refit = false) {
   if (w[1] & 2u)
     return ctx->fail(RT_ERR_LIMIT, "a leaf's start/count does not fit the WIDE64 leaf reference (start < 2^" + std::to_string(b.leaf_shift) +
                                    ", count <= " + std::to_string(b.leaf_shift >= 31 ? 1u : (1u << (31 - b.leaf_shift))) + ")");
-  if (w[1] & 4u) return ctx->fail(RT_ERR_INVALID, "node buffer has an out-of-range child index");
+  if (w[1] & 4u) return ctx->fail(RT_ERR_INVALID, "node buffer has an out-of-range child index or a leaf range outside the triangle buffer");
   b.root_ref = w[0];
   ctx->have_bvh = true;
   ctx->bvh_serial += 1;
@@ -297,6 +297,9 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
   const bool v2 = ctx->node_encoding == RT_NODES_V2;
   DeviceGuard g(ctx->device);
   JOIN_FRAMES();
+  // the buffers of the previous BVH are reallocated / overwritten below: until this build has succeeded there is no BVH
+  // (an early return must not leave have_bvh pointing at freed or half-written records)
+  ctx->have_bvh = false; ctx->built = false; ctx->tri_uv_n = 0;
   hipStream_t s = ctx->stream;
   HIPCHK(ctx->bounds_enc.ensure(rt_bounds_words())); HIPCHK(ctx->bounds_f.ensure(8)); HIPCHK(ctx->centroids.ensure((size_t)T * 3));
   HIPCHK(ctx->codes.ensure(T)); HIPCHK(ctx->keys_a.ensure(T)); HIPCHK(ctx->keys_b.ensure(T));
@@ -480,6 +483,14 @@ extern "C" int rt_set_bvh(rt_ctx* ctx, const float* nodes, uint32_t n_nodes, con
   return finish_bvh(ctx);
 }
 
+// Cache-file trailer: 16 bytes {magic "RTBV", n_nodes, n_tri, node encoding} behind the three raw buffers.  Written only
+// where the header-less file could not be read back: trees with N != 2T-1 (multi-triangle leaves, e.g. the reference's
+// SAH builder with leaf > 1, script.js:285-513) and v2 node records.  A leaf-1 v1 tree stays the raw f32 dump that can be
+// bound to the reference's buffers as it is.
+namespace {
+constexpr uint32_t BVH_FILE_MAGIC = 0x56425452u;   // "RTBV" little-endian
+}
+
 extern "C" int rt_save_bvh(rt_ctx* ctx, const char* path) {
   NEED_BVH();
   if (!path) return ctx->fail(RT_ERR_INVALID, "rt_save_bvh: NULL path");
@@ -491,9 +502,14 @@ extern "C" int rt_save_bvh(rt_ctx* ctx, const char* path) {
   if (rc != RT_OK) return rc;
   FILE* f = std::fopen(path, "wb");
   if (!f) return ctx->fail(RT_ERR_IO, std::string("cannot open for writing: ") + path);
-  const size_t w = std::fwrite(buf.data(), sizeof(float), buf.size(), f);
-  std::fclose(f);
-  if (w != buf.size()) return ctx->fail(RT_ERR_IO, std::string("short write: ") + path);
+  size_t w = std::fwrite(buf.data(), sizeof(float), buf.size(), f);
+  bool ok = w == buf.size();
+  if (ok && (N != 2 * T - 1 || ctx->bvh.v2)) {
+    const uint32_t tr[4] = {BVH_FILE_MAGIC, (uint32_t)N, (uint32_t)T, (uint32_t)(ctx->bvh.v2 ? RT_NODES_V2 : RT_NODES_V1)};
+    ok = std::fwrite(tr, sizeof(uint32_t), 4, f) == 4;
+  }
+  ok = (std::fclose(f) == 0) && ok;
+  if (!ok) return ctx->fail(RT_ERR_IO, std::string("short write: ") + path);
   return RT_OK;
 }
 
@@ -505,13 +521,25 @@ extern "C" int rt_load_bvh(rt_ctx* ctx, const char* path) {
   std::fseek(f, 0, SEEK_END);
   const long sz = std::ftell(f);
   std::fseek(f, 0, SEEK_SET);
-  // 32 B x (2T-1) + 96 B x T = 160 T - 32
-  if (sz <= 0 || (sz + 32) % 160 != 0) { std::fclose(f); return ctx->fail(RT_ERR_IO, "not a BVH cache file (size is not 160*T-32 bytes)"); }
-  const size_t T = (size_t)(sz + 32) / 160, N = 2 * T - 1;
+  if (sz <= 0 || sz % 4 != 0) { std::fclose(f); return ctx->fail(RT_ERR_IO, "not a BVH cache file (empty, or not a whole number of 32-bit words)"); }
   std::vector<float> buf((size_t)sz / 4);
   const size_t r = std::fread(buf.data(), 1, (size_t)sz, f);
   std::fclose(f);
   if (r != (size_t)sz) return ctx->fail(RT_ERR_IO, "short read");
+  size_t T = 0, N = 0;
+  if (sz >= 16 + 32 + 96) {                          // trailer {magic, N, T, encoding} consistent with the file size?
+    uint32_t tr[4];
+    std::memcpy(tr, buf.data() + buf.size() - 4, sizeof(tr));
+    if (tr[0] == BVH_FILE_MAGIC && (tr[3] == RT_NODES_V1 || tr[3] == RT_NODES_V2) && tr[1] > 0 && tr[2] > 0 &&
+        32ull * tr[1] + 96ull * tr[2] + 16ull == (unsigned long long)sz) {
+      N = tr[1]; T = tr[2];
+      ctx->node_encoding = (int)tr[3];               // the file says how its slots A / B are encoded
+    }
+  }
+  if (N == 0) {                                      // header-less: 32 B x (2T-1) + 96 B x T = 160 T - 32, encoding = the context's setting
+    if ((sz + 32) % 160 != 0) return ctx->fail(RT_ERR_IO, "not a BVH cache file (no trailer, and the size is not 160*T-32 bytes)");
+    T = (size_t)(sz + 32) / 160; N = 2 * T - 1;
+  }
   return rt_set_bvh(ctx, buf.data(), (uint32_t)N, buf.data() + 8 * N, buf.data() + 8 * N + 12 * T, (uint32_t)T);
 }
 
@@ -556,7 +584,7 @@ extern "C" int rt_bvh_adopt_device(rt_ctx* ctx, const rt_bvh_view* v) {
   ctx->bvh.tri_pos = static_cast<float*>(v->d_tri_pos);
   ctx->bvh.tri_nor = static_cast<float*>(v->d_tri_nor);
   ctx->bvh.n_nodes = v->n_nodes; ctx->bvh.n_tri = v->n_tri; ctx->bvh.owns_interchange = false;
-  return finish_bvh(ctx);   // the pack kernel range-checks every child / leaf index on the device
+  return finish_bvh(ctx);   // the pack kernel range-checks every child index and every leaf's [start, start + count) on the device
 }
 
 // ================================================================ material / texture shading (extension)
@@ -755,7 +783,9 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
   p.nodes = ctx->bvh.nodes; p.tri_pos = ctx->bvh.tri_pos; p.tri_nor = ctx->bvh.tri_nor;
   p.wide = ctx->bvh.wide; p.tri_pre = ctx->bvh.tri_pre; p.root_ref = ctx->bvh.root_ref; p.leaf_shift = ctx->bvh.leaf_shift;
   p.nodes_v2 = ctx->bvh.v2 ? 1 : 0;
-  p.step_budget = ctx->bvh.n_nodes + 64u;
+  // one budget step per loop iteration of the walk: WIDE64 spends one per internal record AND one per leaf triangle
+  // (closest_wide advances leaf_j one triangle per iteration), AOS32 one per node visit with twice this budget
+  p.step_budget = ctx->bvh.n_nodes + ctx->bvh.n_tri + 64u;
   if (opts->flags & RT_FLAG_TEXTURED) {
     if (ctx->tri_uv_n == 0 || ctx->tri_uv_n != ctx->bvh.n_tri)
       return ctx->fail(RT_ERR_INVALID, "RT_FLAG_TEXTURED: no surface records for the current BVH (rt_set_surface before rt_build_lbvh, or rt_set_tri_uv)");

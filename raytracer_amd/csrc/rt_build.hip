@@ -507,30 +507,34 @@ __global__ __launch_bounds__(BLK) void k_refit_verify(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------- traversal layout
-RT_DEV uint32_t make_ref(const float4 a, const float4 b, int node, int leaf_shift, bool v2, uint32_t* err) {
+RT_DEV uint32_t make_ref(const float4 a, const float4 b, int node, int leaf_shift, bool v2, uint32_t n_tri, uint32_t* err) {
   if (dec_is_leaf(v2, b.w)) {                         // leaf test of fetchCachedNode, compute.wgsl:75
     const uint32_t start = (uint32_t)dec_index(v2, a.w), count = (uint32_t)dec_count(v2, b.w);
     const uint32_t max_start = (leaf_shift >= 31) ? 0x7FFFFFFFu : ((1u << leaf_shift) - 1u);
     const uint32_t max_count = (leaf_shift >= 31) ? 1u : (1u << (31 - leaf_shift));
     if (start > max_start || count < 1 || count > max_count) { atomicOr(err, 2u); return 0xFFFFFFFFu; }
+    // the leaf's triangles must exist: k_render reads tri_pre / tri_nor [start, start + count) (adopted device buffers
+    // never pass the host's validate_nodes)
+    if ((unsigned long long)start + count > n_tri) { atomicOr(err, 4u); return 0xFFFFFFFFu; }
     return 0x80000000u | ((count - 1u) << leaf_shift) | start;
   }
   return (uint32_t)node;
 }
 
 __global__ __launch_bounds__(BLK) void k_pack_wide(const float* __restrict__ nodes, uint32_t n_nodes, float4* __restrict__ wide,
-                                                   uint32_t n_wide, int leaf_shift, bool v2, uint32_t* root_ref, uint32_t* err) {
+                                                   uint32_t n_wide, int leaf_shift, bool v2, uint32_t n_tri, uint32_t* root_ref,
+                                                   uint32_t* err) {
   const uint32_t i = blockIdx.x * BLK + threadIdx.x;
   if (i >= n_nodes) return;
   const float4* nd = reinterpret_cast<const float4*>(nodes);
   const float4 a = nd[2 * (size_t)i], b = nd[2 * (size_t)i + 1];
-  if (i == 0) *root_ref = make_ref(a, b, 0, leaf_shift, v2, err);
+  if (i == 0) *root_ref = make_ref(a, b, 0, leaf_shift, v2, n_tri, err);
   if (dec_is_leaf(v2, b.w)) return;
   const int c0 = dec_index(v2, a.w), c1 = dec_index(v2, b.w);
   if (i >= n_wide || c0 < 0 || c1 < 0 || (uint32_t)c0 >= n_nodes || (uint32_t)c1 >= n_nodes) { atomicOr(err, 4u); return; }
   const float4 a0 = nd[2 * (size_t)c0], b0 = nd[2 * (size_t)c0 + 1];
   const float4 a1 = nd[2 * (size_t)c1], b1 = nd[2 * (size_t)c1 + 1];
-  const uint32_t r0 = make_ref(a0, b0, c0, leaf_shift, v2, err), r1 = make_ref(a1, b1, c1, leaf_shift, v2, err);
+  const uint32_t r0 = make_ref(a0, b0, c0, leaf_shift, v2, n_tri, err), r1 = make_ref(a1, b1, c1, leaf_shift, v2, n_tri, err);
   wide[4 * (size_t)i + 0] = make_float4(a0.x, a0.y, a0.z, __uint_as_float(r0));
   wide[4 * (size_t)i + 1] = make_float4(b0.x, b0.y, b0.z, __uint_as_float(r1));
   wide[4 * (size_t)i + 2] = make_float4(a1.x, a1.y, a1.z, 0.0f);
@@ -602,6 +606,6 @@ void rt_launch_refit(const RtBuildBuffers& b, float* nodes, float* tri_pos, floa
 // root_ref / err words live right behind the bounds words: see rt_api.hip (scratch[0], scratch[1])
 void rt_launch_pack_impl(const RtBvhDev& bvh, uint32_t* d_root_ref, uint32_t* d_err, hipStream_t s) {
   hipLaunchKernelGGL(k_pack_wide, dim3((bvh.n_nodes + BLK - 1) / BLK), dim3(BLK), 0, s, bvh.nodes, bvh.n_nodes, bvh.wide,
-                     bvh.n_wide, bvh.leaf_shift, bvh.v2, d_root_ref, d_err);
+                     bvh.n_wide, bvh.leaf_shift, bvh.v2, bvh.n_tri, d_root_ref, d_err);
   hipLaunchKernelGGL(k_pack_tris, dim3((bvh.n_tri + BLK - 1) / BLK), dim3(BLK), 0, s, bvh.tri_pos, bvh.n_tri, bvh.tri_pre);
 }

@@ -52,7 +52,7 @@ struct RtRenderParams {
   uint32_t root_ref;
   int      leaf_shift;
   int      nodes_v2;               // encoding of `nodes` (read by the AOS32 walk only)
-  uint32_t step_budget;            // n_nodes + 64
+  uint32_t step_budget;            // n_nodes + n_tri + 64: loop iterations no valid tree needs more of
   float    U[44];
   int mode, gi_samples, gi_bounces, soft_samples, max_stack;
   uint32_t width, height;
