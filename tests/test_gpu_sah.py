@@ -85,7 +85,7 @@ def test_single_leaf_of_256_triangles(gpu_ctx, oracle, rt):
     gpu_ctx.set_bvh(nodes, tp, tn)
     out = _check_both_layouts(gpu_ctx, oracle, rt, nodes, tp, tn, _soup_view(rt), "256-triangle leaf")
     hit = out["hit_tri"][out["hit_tri"] != 0xFFFFFFFF]
-    assert hit.size > 500 and hit.max() >= 200           # triangles from the back of the leaf win pixels too
+    assert hit.size > 200 and hit.max() >= 200           # triangles from the back of the leaf win pixels too
 
 
 @pytest.mark.parametrize("leaf", [8, 64])
