@@ -217,6 +217,21 @@ int rt_render(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* opts,
 int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* opts,
                      void* d_rgba8, void* d_hit_tri, void* d_hit_t, rt_render_stats* out);
 uint32_t rt_packed_rows(uint32_t height, int32_t stripe_rows, int32_t stripe_rank, int32_t stripe_world);
+
+/* rt_render_device for callers that cannot allocate device memory: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  No counterpart in the reference (a WebGPU page never sees an allocator).  Same
+ * kernels, same results as rt_render_device bit for bit; the frame's scratch (compacted pixel list, tile masks, queue
+ * heads, per-block counters) lives in ONE static device array of 38.6 MB that every GPU the library runs on holds until
+ * the process ends, instead of the lazily grown allocations of rt_render_device.  Calls no hipMalloc / hipFree.
+ * Limits: local_rows x width <= 3840 x 2160 pixels (the whole image, or this rank's stripe share) and at most 145 984
+ * 8x8 tiles - RT_ERR_LIMIT beyond that; asynchronous on rt_stream(), always (frames in flight do not apply, there are no
+ * stats); no frame-coherent scheduling hints (frames run at the unhinted speed); RT_MODE_PT runs one lane per pixel (the
+ * PT split needs large term buffers); with RT_FLAG_TEXTURED the material and texture tables must already exist
+ * (rt_set_materials / rt_set_texture).  The array is shared by every context on the same GPU and keeps the last call's
+ * contents (each call rewrites what it reads): calls that overlap on one GPU - two contexts, two processes' worth of
+ * streams - race; serialise them. */
+int rt_render_device_noalloc(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* opts,
+                             void* d_rgba8, void* d_hit_tri, void* d_hit_t);
 /* De-interleave `world` packed stripe buffers (concatenated rank-major, each
  * rows_per_rank x width x elem_bytes) into a full image; all pointers are device memory. */
 int rt_deinterleave_device(rt_ctx* ctx, const void* d_packed, void* d_image, uint32_t width, uint32_t height,

@@ -292,6 +292,12 @@ class Context:
                                       C.c_void_p(d_hit_t or None), C.byref(st) if want_stats else None))
         return st.as_dict() if want_stats else None
 
+    def render_device_noalloc(self, uniforms, opts, d_rgba8=0, d_hit_tri=0, d_hit_t=0):
+        """rt_render_device without any device allocation (static scratch, <= 3840x2160 pixels per call); asynchronous."""
+        U = np.ascontiguousarray(uniforms, np.float32)
+        self._chk(_L.rt_render_device_noalloc(self._h, _vp(U), C.byref(opts), C.c_void_p(d_rgba8 or None),
+                                              C.c_void_p(d_hit_tri or None), C.c_void_p(d_hit_t or None)))
+
     def deinterleave_device(self, d_packed, d_image, width, height, elem_bytes, stripe_rows, world, rows_per_rank):
         self._chk(_L.rt_deinterleave_device(self._h, C.c_void_p(d_packed), C.c_void_p(d_image), width, height, elem_bytes,
                                             stripe_rows, world, rows_per_rank))

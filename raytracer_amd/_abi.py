@@ -30,6 +30,7 @@ SYMBOLS = [
     "rt_profile_begin", "rt_profile_end", "rt_set_node_encoding", "rt_get_node_encoding",
     "rt_set_surface", "rt_get_tri_uv", "rt_set_tri_uv", "rt_set_materials", "rt_set_texture", "rt_tri_uv_device",
     "rt_adopt_tri_uv_device", "rt_tri_uv_export_device", "rt_set_frames_in_flight", "rt_frames_join", "rt_set_coherent_scheduling",
+    "rt_render_device_noalloc",
 ]
 
 
@@ -139,6 +140,7 @@ def load():
         "rt_render_opts_for_mode": (C.c_int, [C.POINTER(RenderOpts), C.c_int]),
         "rt_render": (C.c_int, [vp, vp, C.POINTER(RenderOpts), vp, vp, vp, C.POINTER(RenderStats)]),
         "rt_render_device": (C.c_int, [vp, vp, C.POINTER(RenderOpts), vp, vp, vp, C.POINTER(RenderStats)]),
+        "rt_render_device_noalloc": (C.c_int, [vp, vp, C.POINTER(RenderOpts), vp, vp, vp]),
         "rt_packed_rows": (u32, [u32, i32, i32, i32]),
         "rt_deinterleave_device": (C.c_int, [vp, vp, vp, u32, u32, u32, i32, i32, u32]),
         "rt_bvh_view_get": (C.c_int, [vp, C.POINTER(BvhView)]),

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -31,9 +32,49 @@ struct DevBuf {
 };
 }  // namespace
 
+// ---------------------------------------------------------------- rt_render_device_noalloc: static device scratch
+// The frame pipeline's scratch (compacted pixel list, per-tile class masks, per-block totals, queue heads, per-block
+// counters) for callers that cannot allocate: one file-scope device array per GPU, held until the process ends.  Host
+// code never uses the array's NAME as an address (it is a host-side stand-in): rt_create asks the runtime for the
+// device address once per device (hipGetSymbolAddress, with that device current) and everything else - kernel
+// arguments, hipMemsetAsync - uses that pointer.
+namespace {
+constexpr uint32_t NOALLOC_MAX_PIXELS = 3840u * 2160u;                 // one 4K frame (or stripe share) per call
+constexpr uint32_t NOALLOC_MAX_TILES = NOALLOC_MAX_PIXELS / 64u + 16384u;   // 8x8 tiles incl. ragged right / bottom edges
+constexpr uint32_t NOALLOC_MAX_GRID = 4096u;                           // >= rt_render_grid(n_cu) blocks (checked)
+constexpr size_t NOALLOC_LIST_BYTES = sizeof(uint32_t) * (size_t)NOALLOC_MAX_PIXELS;
+constexpr size_t NOALLOC_STATS_BYTES = sizeof(unsigned long long) * (8 + 32 + (size_t)NOALLOC_MAX_GRID * 8 + (size_t)RT_N_CLASS * NOALLOC_MAX_TILES);
+constexpr size_t NOALLOC_TC_BYTES = sizeof(uint32_t) * (2 * 4096 + 32 + 64 + (size_t)RT_N_CLASS * (NOALLOC_MAX_TILES / 64 + 1));
+constexpr size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+constexpr size_t NOALLOC_OFF_STATS = align256(NOALLOC_LIST_BYTES);
+constexpr size_t NOALLOC_OFF_TC = NOALLOC_OFF_STATS + align256(NOALLOC_STATS_BYTES);
+constexpr size_t NOALLOC_BYTES = NOALLOC_OFF_TC + align256(NOALLOC_TC_BYTES);      // ~38.6 MB
+}  // namespace
+static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES];
+namespace {
+constexpr int NOALLOC_MAX_DEVICES = 64;
+unsigned char* g_scratch_ptr[NOALLOC_MAX_DEVICES] = {};                // device address of `scratch` on each GPU (its own copy, its own address)
+std::mutex g_scratch_mu;
+// Called by rt_create with `dev` current.  Once per device.
+hipError_t noalloc_scratch_init(int dev, unsigned char** out) {
+  *out = nullptr;
+  if (dev < 0 || dev >= NOALLOC_MAX_DEVICES) return hipSuccess;       // such a device simply has no no-alloc entry point
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    unsigned char* ptr = nullptr;
+    const hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    g_scratch_ptr[dev] = ptr;
+  }
+  *out = g_scratch_ptr[dev];
+  return hipSuccess;
+}
+}  // namespace
+
 struct rt_ctx {
   int device = 0;
   int n_cu = 256;
+  unsigned char* noalloc_scratch = nullptr;   // this GPU's copy of the static scratch array (rt_render_device_noalloc)
   hipStream_t stream = nullptr;
   hipEvent_t ev[8] = {};
   std::string err;
@@ -208,6 +249,9 @@ extern "C" int rt_create(rt_ctx** out, const char* backend, const int* device_id
   if ((e = hipSetDevice(dev)) != hipSuccess) { g_create_error = hipGetErrorString(e); delete ctx; return RT_ERR_HIP; }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+  if ((e = noalloc_scratch_init(dev, &ctx->noalloc_scratch)) != hipSuccess) {
+    g_create_error = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e); delete ctx; return RT_ERR_HIP;
+  }
   if ((e = hipStreamCreate(&ctx->stream)) != hipSuccess) { g_create_error = hipGetErrorString(e); delete ctx; return RT_ERR_HIP; }
   for (auto& ev : ctx->ev) (void)hipEventCreate(&ev);
   if (const char* e = std::getenv("RTCORE_COHERENT_SCHEDULING")) ctx->coherent_scheduling = std::atoi(e) != 0;
@@ -767,8 +811,12 @@ int check_opts(rt_ctx* ctx, const rt_render_opts* o) {
 }
 }  // namespace
 
-extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* opts, void* d_rgba8, void* d_hit_tri,
-                                void* d_hit_t, rt_render_stats* out) {
+namespace {
+// One frame.  noalloc = false: rt_render_device (scratch in lazily grown per-frame-slot allocations).  noalloc = true:
+// rt_render_device_noalloc - the same kernels with this GPU's static scratch array carved up instead; no hipMalloc /
+// hipFree anywhere on the path, hence no frame slots (the array is one per GPU), no scheduling hints, no PT split, no stats.
+int render_frame(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* opts, void* d_rgba8, void* d_hit_tri,
+                 void* d_hit_t, rt_render_stats* out, bool noalloc) {
   NEED_BVH();
   if (!uniforms) return ctx->fail(RT_ERR_INVALID, "uniforms are NULL");
   int rc = check_opts(ctx, opts);
@@ -794,7 +842,12 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
       if (t >= 0 && ((uint32_t)t >= ctx->n_textures || ctx->tex_host[t].texels == nullptr))
         return ctx->fail(RT_ERR_INVALID, "RT_FLAG_TEXTURED: material " + std::to_string(i) + " names texture slot " + std::to_string(t) + ", which was never set");
     }
-    HIPCHK(ctx->materials.ensure(1)); HIPCHK(ctx->tex_table.ensure(RT_MAX_TEXTURES));
+    if (noalloc) {
+      if (!ctx->materials.p || !ctx->tex_table.p)
+        return ctx->fail(RT_ERR_INVALID, "rt_render_device_noalloc with RT_FLAG_TEXTURED: call rt_set_materials and rt_set_texture first (their tables are not allocated here)");
+    } else {
+      HIPCHK(ctx->materials.ensure(1)); HIPCHK(ctx->tex_table.ensure(RT_MAX_TEXTURES));
+    }
     p.tri_uv = reinterpret_cast<const float4*>(ctx->tri_uv.p); p.materials = ctx->materials.p; p.textures = ctx->tex_table.p;
     p.n_materials = ctx->n_materials; p.n_textures = ctx->n_textures;
   }
@@ -815,7 +868,7 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
   // Frame slot + stream.  Synchronous frames (stats wanted) and contexts with one frame in flight use the context
   // stream and slot 0 after joining whatever is still running; asynchronous frames with two in flight alternate
   // between the two frame streams, each behind everything queued on the context stream so far.
-  const bool overlap = ctx->frames_in_flight >= 2 && out == nullptr;
+  const bool overlap = !noalloc && ctx->frames_in_flight >= 2 && out == nullptr;
   int slot = 0;
   hipStream_t s = ctx->stream;
   if (overlap) {
@@ -827,15 +880,34 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
   } else {
     JOIN_FRAMES();
   }
-  HIPCHK(ctx->r_tile_counter[slot].ensure(2 * (size_t)rt_shard_words() + 32 + 64 + (size_t)rt_n_class() * cull_blocks));
-  HIPCHK(ctx->r_stats[slot].ensure(8 + 32 + (size_t)rt_render_grid(ctx->n_cu) * 8 + (size_t)rt_n_class() * p.n_tiles));
-  HIPCHK(ctx->r_list[slot].ensure((size_t)p.local_rows * p.width));
+  const size_t tc_words = 2 * (size_t)rt_shard_words() + 32 + 64 + (size_t)rt_n_class() * cull_blocks;
+  const size_t st_words = 8 + 32 + (size_t)rt_render_grid(ctx->n_cu) * 8 + (size_t)rt_n_class() * p.n_tiles;
+  const size_t list_words = (size_t)p.local_rows * p.width;
+  uint32_t* sc_tc; unsigned long long* sc_st; uint32_t* sc_list;
+  if (noalloc) {
+    if (!ctx->noalloc_scratch) return ctx->fail(RT_ERR_INVALID, "rt_render_device_noalloc: no static scratch on this device (device id >= 64)");
+    if (list_words > NOALLOC_MAX_PIXELS || p.n_tiles > NOALLOC_MAX_TILES || rt_render_grid(ctx->n_cu) > NOALLOC_MAX_GRID ||
+        rt_n_class() != (uint32_t)RT_N_CLASS || list_words * sizeof(uint32_t) > NOALLOC_LIST_BYTES ||
+        st_words * sizeof(unsigned long long) > NOALLOC_STATS_BYTES || tc_words * sizeof(uint32_t) > NOALLOC_TC_BYTES)
+      return ctx->fail(RT_ERR_LIMIT, "rt_render_device_noalloc: the frame (or this rank's stripe share) has " + std::to_string(list_words) +
+                                     " pixels / " + std::to_string(p.n_tiles) + " 8x8 tiles; the static scratch holds at most " +
+                                     std::to_string(NOALLOC_MAX_PIXELS) + " pixels (3840x2160) / " + std::to_string(NOALLOC_MAX_TILES) +
+                                     " tiles - use rt_render_device");
+    sc_list = reinterpret_cast<uint32_t*>(ctx->noalloc_scratch);
+    sc_st = reinterpret_cast<unsigned long long*>(ctx->noalloc_scratch + NOALLOC_OFF_STATS);
+    sc_tc = reinterpret_cast<uint32_t*>(ctx->noalloc_scratch + NOALLOC_OFF_TC);
+  } else {
+    HIPCHK(ctx->r_tile_counter[slot].ensure(tc_words));
+    HIPCHK(ctx->r_stats[slot].ensure(st_words));
+    HIPCHK(ctx->r_list[slot].ensure(list_words));
+    sc_tc = ctx->r_tile_counter[slot].p; sc_st = ctx->r_stats[slot].p; sc_list = ctx->r_list[slot].p;
+  }
   p.shard_stride = rt_shard_stride();
   p.blocks_per_cu_cap = overlap ? 2u : 0u;
   p.shard_group = 8;
   // PT split (sample-parallel GI) wherever its fixed-size term registers suffice; RTCORE_PT_SPLIT=0 keeps one lane per pixel
   {
-    bool split = opts->mode == RT_MODE_PT && opts->gi_samples >= 2 && opts->gi_bounces >= 1 && opts->gi_bounces <= 4;
+    bool split = !noalloc && opts->mode == RT_MODE_PT && opts->gi_samples >= 2 && opts->gi_bounces >= 1 && opts->gi_bounces <= 4;
     if (const char* e = std::getenv("RTCORE_PT_SPLIT")) split = split && std::atoi(e) != 0;
     p.pt_cap = 0;
     if (split && p.n_tiles > 0) p.pt_cap = 1;   // sized below, once shard_group is final
@@ -851,17 +923,20 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
       p.pt_recs = ctx->pt_recs[slot].p; p.pt_terms = ctx->pt_terms[slot].p;
     }
   }
-  p.shard_heads = ctx->r_tile_counter[slot].p; p.list_count = ctx->r_tile_counter[slot].p + rt_shard_words();
-  p.pt_heads = ctx->r_tile_counter[slot].p + rt_shard_words() + 32;
+  // Everything k_render reads is (re)written by this frame's own k_cull / k_compact first: the queue heads are zeroed by
+  // k_cull, block totals / masks of every tile / the list and its counts are written in full.  (Nothing else has to start
+  // at zero, which is what lets the no-alloc variant reuse one array call after call.)
+  p.shard_heads = sc_tc; p.list_count = sc_tc + rt_shard_words();
+  p.pt_heads = sc_tc + rt_shard_words() + 32;
   p.pt_count = p.pt_heads + rt_shard_words();
   p.block_total = p.pt_count + 64;
-  p.list = ctx->r_list[slot].p;
-  p.stats = ctx->r_stats[slot].p; p.stats_partial = ctx->r_stats[slot].p + 8 + 32;
-  p.class_hist = reinterpret_cast<uint32_t*>(ctx->r_stats[slot].p + 8);   // 64 u32
-  p.masks = ctx->r_stats[slot].p + 8 + 32 + (size_t)rt_render_grid(ctx->n_cu) * 8;
+  p.list = sc_list;
+  p.stats = sc_st; p.stats_partial = sc_st + 8 + 32;
+  p.class_hist = reinterpret_cast<uint32_t*>(sc_st + 8);   // 64 u32
+  p.masks = sc_st + 8 + 32 + (size_t)rt_render_grid(ctx->n_cu) * 8;
   // frame-coherent scheduling hints: one cost class per pixel of this image shape, cleared whenever the shape, the
   // striping or the BVH changes (hints of another view are merely useless, never wrong: they only order the work)
-  if (ctx->coherent_scheduling) {
+  if (ctx->coherent_scheduling && !noalloc) {
     const uint64_t key = ((uint64_t)p.width << 40) ^ ((uint64_t)p.local_rows << 20) ^ ((uint64_t)p.stripe_rank << 8) ^ (uint64_t)p.stripe_world ^
                          ((uint64_t)ctx->bvh_serial << 52);
     const size_t n_px = (size_t)p.local_rows * p.width;
@@ -949,6 +1024,18 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
     }
   }
   return RT_OK;
+}
+}  // namespace
+
+extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* opts, void* d_rgba8, void* d_hit_tri,
+                                void* d_hit_t, rt_render_stats* out) {
+  return render_frame(ctx, uniforms, opts, d_rgba8, d_hit_tri, d_hit_t, out, /*noalloc=*/false);
+}
+
+// No hipMalloc / hipFree / allocating routine on this path: scratch = this GPU's static array (see the top of this file).
+extern "C" int rt_render_device_noalloc(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* opts, void* d_rgba8,
+                                        void* d_hit_tri, void* d_hit_t) {
+  return render_frame(ctx, uniforms, opts, d_rgba8, d_hit_tri, d_hit_t, nullptr, /*noalloc=*/true);
 }
 
 extern "C" int rt_set_coherent_scheduling(rt_ctx* ctx, int on) {

@@ -129,6 +129,9 @@ void rt_launch_refit(const RtBuildBuffers& b, float* nodes, float* tri_pos, floa
 void rt_launch_pack_impl(const RtBvhDev& bvh, uint32_t* d_root_ref, uint32_t* d_err, hipStream_t s);
 
 // ---------------------------------------------------------------- traversal (rt_trace.hip)
+#ifndef RT_N_CLASS
+#define RT_N_CLASS 4              // cost classes of the pixel list (3 .. 8), see rt_trace.hip
+#endif
 uint32_t rt_render_grid(int n_cu);   // blocks of the persistent phase-B grid
 uint32_t rt_cull_blocks(uint32_t n_tiles);
 uint32_t rt_n_class();            // cost classes of the pixel list (rt_trace.hip N_CLASS)

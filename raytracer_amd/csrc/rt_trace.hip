@@ -702,9 +702,6 @@ __global__ void k_stats_final(const RtRenderParams p, uint32_t n_blocks, uint32_
 constexpr int CULL_TPB = 64;          // tiles per k_cull / k_compact block: 16 rounds x 4 waves
 constexpr int N_SHARD = 64;           // phase-B queue shards, one 128-byte line of queue state each
 constexpr int SHARD_STRIDE = 32;      // uint32 words between shard heads: one 128-byte line each
-#ifndef RT_N_CLASS
-#define RT_N_CLASS 4
-#endif
 constexpr int N_CLASS = RT_N_CLASS;   // cost classes of the pixel list: 0 cheap / unknown, 1 normal, 2 .. N-1 quantile bands of the non-cheap pixels
 static_assert(N_CLASS >= 3 && N_CLASS <= 8, "class_share[] holds N_CLASS - 2 <= 6 entries");
 static int shard_stride_words() { return SHARD_STRIDE; }

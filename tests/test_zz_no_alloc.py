@@ -1,0 +1,120 @@
+"""rt_render_device_noalloc (include/rtcore.h): the entry point that allocates nothing.  Its frame must equal
+rt_render_device's bit for bit — image, hit ids, hit distances — on two calls in a row, the second with a SMALLER input
+(the static scratch array keeps the first call's contents: stale list entries / masks / queue heads must not leak into
+the next frame), then a larger one again, striped, textured and in PT mode; sizes beyond the array are refused."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PLANE_VIEW = dict(cam_pos=(0.0, 0.0, 1.3), rot_deg=(-90.0, 0.0, 0.0), scale=(2.5, 2.5, 2.5))
+
+
+def _frame(ctx, rt, torch, U, opts, noalloc, rows=None):
+    w, h = int(U[36]), int(U[37])
+    rows = h if rows is None else rows
+    dev = torch.device("cuda:0")
+    rgba = torch.full((rows, w), 0x01020304, dtype=torch.int32, device=dev)
+    tri = torch.full((rows, w), 7, dtype=torch.int32, device=dev)
+    t = torch.full((rows, w), -1.0, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    if noalloc:
+        ctx.render_device_noalloc(U, opts, rgba.data_ptr(), tri.data_ptr(), t.data_ptr())
+    else:
+        ctx.render_device(U, opts, rgba.data_ptr(), tri.data_ptr(), t.data_ptr(), want_stats=False)
+    ctx.synchronize()
+    return rgba.cpu().numpy(), tri.cpu().numpy(), t.cpu().numpy()
+
+
+def _same(a, b, what):
+    for x, y, k in zip(a, b, ("rgba8", "hit_tri", "hit_t")):
+        assert np.array_equal(x, y), f"{what}: {k} differs between rt_render_device_noalloc and rt_render_device"
+
+
+def test_noalloc_equals_render_device_on_consecutive_calls(rt, plane_mesh, oracle):
+    import torch
+    ctx = rt.Context(0)
+    try:
+        ctx.set_mesh(plane_mesh)
+        ctx.build_lbvh()
+        shadow = rt.render_opts(mode=rt.MODE_SHADOW)
+        big = rt.make_uniforms(640, 360, **PLANE_VIEW)
+        small = rt.make_uniforms(203, 117, **PLANE_VIEW)          # ragged tiles, fewer pixels than the call before
+        ref_big = _frame(ctx, rt, torch, big, shadow, noalloc=False)
+        ref_small = _frame(ctx, rt, torch, small, shadow, noalloc=False)
+        # two calls in a row, the second smaller; then the large one again over the small one's leftovers
+        _same(_frame(ctx, rt, torch, big, shadow, noalloc=True), ref_big, "640x360")
+        _same(_frame(ctx, rt, torch, small, shadow, noalloc=True), ref_small, "203x117 after 640x360")
+        _same(_frame(ctx, rt, torch, big, shadow, noalloc=True), ref_big, "640x360 after 203x117")
+        hit = ref_big[1].view(np.uint32) != 0xFFFFFFFF
+        assert 0.2 < hit.mean() < 0.95
+        # and the frame is the oracle's (hit ids exact, image identical)
+        b = oracle.build_lbvh(plane_mesh.positions, plane_mesh.normals, plane_mesh.vert_idx, plane_mesh.norm_idx)
+        exp, _ = oracle.render(b["nodes"], b["tri_pos"], b["tri_nor"], small, mode=1, n_threads=8)
+        got = _frame(ctx, rt, torch, small, shadow, noalloc=True)
+        assert np.array_equal(got[1].view(np.uint32), exp["hit_tri"])
+        assert np.array_equal(got[0].view(np.uint8).reshape(117, 203, 4), exp["rgba8"])
+        assert np.array_equal(got[2], exp["hit_t"])
+
+        # PT (one lane per pixel here, PT split in rt_render_device: same arithmetic), AOS32, stripes
+        pt = rt.render_opts(mode=rt.MODE_PT, gi_samples=4)
+        tiny = rt.make_uniforms(96, 64, **PLANE_VIEW)
+        _same(_frame(ctx, rt, torch, tiny, pt, noalloc=True), _frame(ctx, rt, torch, tiny, pt, noalloc=False), "PT 96x64")
+        aos = rt.render_opts(mode=rt.MODE_SHADOW, layout=rt.LAYOUT_AOS32)
+        _same(_frame(ctx, rt, torch, small, aos, noalloc=True), ref_small, "AOS32")
+        for rank in range(3):
+            so = rt.render_opts(mode=rt.MODE_SHADOW, stripe_rows=16, stripe_rank=rank, stripe_world=3)
+            rows = rt.packed_rows(360, 16, rank, 3)
+            _same(_frame(ctx, rt, torch, big, so, noalloc=True, rows=rows), _frame(ctx, rt, torch, big, so, noalloc=False, rows=rows),
+                  f"stripes of rank {rank}")
+
+        # a second context on the same GPU shares the array: used one after the other it gives the same frame
+        other = rt.Context(0)
+        try:
+            other.set_mesh(plane_mesh)
+            other.build_lbvh()
+            _same(_frame(other, rt, torch, small, shadow, noalloc=True), ref_small, "second context")
+        finally:
+            other.close()
+        _same(_frame(ctx, rt, torch, big, shadow, noalloc=True), ref_big, "first context again")
+    finally:
+        ctx.close()
+
+
+def test_noalloc_textured_and_limits(rt, oracle):
+    import torch
+    from raytracer_amd import scenes
+    ctx = rt.Context(0)
+    try:
+        mesh = rt.normalize_mesh(scenes.s70k())
+        ctx.set_mesh(mesh)
+        ctx.set_surface(mesh)
+        ctx.build_lbvh()
+        U = rt.make_uniforms(480, 270, cam_pos=(0.0, 0.0, 1.3))
+        tex = rt.render_opts(mode=rt.MODE_SHADOW, flags=rt.FLAG_TEXTURED)
+        with pytest.raises(rt.RtError) as e:                     # the tables are not allocated here: refused, not allocated
+            _frame(ctx, rt, torch, U, tex, noalloc=True)
+        assert e.value.code == -1
+        ctx.set_materials(scenes.STANDIN_MATERIALS)
+        ctx.set_texture(0, scenes.procedural_texture(256, 0))
+        ctx.set_texture(1, scenes.procedural_texture(128, 1))
+        _same(_frame(ctx, rt, torch, U, tex, noalloc=True), _frame(ctx, rt, torch, U, tex, noalloc=False), "textured")
+
+        # the documented maximum works, one row more is refused with RT_ERR_LIMIT and nothing is launched
+        full = rt.make_uniforms(3840, 2160, cam_pos=(0.0, 0.0, 1.3))
+        prim = rt.render_opts(mode=rt.MODE_PRIMARY)
+        a = _frame(ctx, rt, torch, full, prim, noalloc=True)
+        b = _frame(ctx, rt, torch, full, prim, noalloc=False)
+        _same(a, b, "3840x2160")
+        too_big = rt.make_uniforms(3840, 2161, cam_pos=(0.0, 0.0, 1.3))
+        with pytest.raises(rt.RtError) as e:
+            ctx.render_device_noalloc(too_big, prim, 0, 0, 0)
+        assert e.value.code == -5 and "3840x2160" in str(e.value)
+        # ... but a stripe share of a larger image fits
+        big = rt.make_uniforms(7680, 4320, cam_pos=(0.0, 0.0, 1.3))
+        so = rt.render_opts(mode=rt.MODE_PRIMARY, stripe_rows=16, stripe_rank=1, stripe_world=5)
+        rows = rt.packed_rows(4320, 16, 1, 5)
+        _same(_frame(ctx, rt, torch, big, so, noalloc=True, rows=rows), _frame(ctx, rt, torch, big, so, noalloc=False, rows=rows),
+              "1/5 stripe share of 7680x4320")
+    finally:
+        ctx.close()
