@@ -69,6 +69,7 @@ def main():
                     help="N > 1: where the frame's stripes are gathered — root = rank 0 only (the viewer's rank: grouped send/recv, each "
                          "byte crosses one xGMI link once), all = every rank (all_gather, N times the traffic)")
     ap.add_argument("--no-fif2", action="store_true", help="skip the extra two-frames-in-flight loop at N = 1")
+    ap.add_argument("--no-legs", action="store_true", help="skip the unhinted and moving-camera legs at N = 1")
     ap.add_argument("--no-texture", action="store_true",
                     help="shade with the reference's constant albedo (compute.wgsl:372) instead of the materials + textures of cfg 3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -149,9 +150,18 @@ def main():
     # one counted launch (untimed): rays + work counters of this rank's share of the frame
     copts = rt.render_opts(mode=mode, layout=layout, flags=rt.FLAG_COUNT_WORK | tflag, **shade,
                            stripe_rows=frame.opts.stripe_rows, stripe_rank=rank, stripe_world=world)
-    cst = ctx.render_device(U, copts, d_rgba8=frame.packed.data_ptr())
-    my_rays = cst["rays_primary"] + cst["rays_shadow"] + cst["rays_bounce"]
-    my_bytes = 32 * cst["box_tests"] + 48 * cst["tri_tests"] + 48 * cst["hit_updates"] + 4 * cst["pixels"]
+    def counted(Uc):
+        """Rays and algorithmic bytes of one frame (this rank's share), from the kernels' own work counters.
+        -> (rays as the reference's loop casts them, rays that enter the tree, bytes of the whole frame, k_render's own bytes).
+        Pixels whose primary ray misses the root box never reach k_render (k_cull disposes of them, most of them through a
+        screen rectangle): k_stats_final counts each as one ray + one box test + one pixel, and those 36 B are NOT k_render's."""
+        c = ctx.render_device(Uc, copts, d_rgba8=frame.packed.data_ptr())
+        culled = c["pixels"] - c["pixels_traced"]
+        rays = c["rays_primary"] + c["rays_shadow"] + c["rays_bounce"]
+        frame_bytes = 32 * c["box_tests"] + 48 * c["tri_tests"] + 48 * c["hit_updates"] + 4 * c["pixels"]
+        return rays, rays - culled, frame_bytes, frame_bytes - 36 * culled
+
+    my_rays, my_rays_traced, my_frame_bytes, my_bytes = counted(U)
 
     for _ in range(args.warmup):
         frame.step(U, want_stats=False)
@@ -192,7 +202,41 @@ def main():
         fif2 = {"value": round(my_rays * args.steps / e2 / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(e2 / args.steps * 1e3, 4)}
         ctx.set_frames_in_flight(1)
 
-    tot = torch.tensor([float(my_rays), float(my_bytes), elapsed, kernel_ms], dtype=torch.float64, device=device)
+    # Two more legs at N = 1, same frame loop, reported beside `value` (never as `value`): the same static view WITHOUT the
+    # frame-coherent scheduling hints, and a view that changes every frame (the model turning 1 degree per frame, as a user
+    # dragging the reference's rotY slider), where last frame's per-pixel hints are a few pixels off.
+    legs = {}
+    if world == 1 and not args.no_legs:
+        def leg(uniforms_list, rays_list, bytes_list):
+            for i in range(args.warmup):
+                frame.step(uniforms_list[i % len(uniforms_list)], want_stats=False)
+            fence()
+            t1 = time.perf_counter()
+            ctx.profile_begin()
+            for i in range(args.steps):
+                frame.step(uniforms_list[i % len(uniforms_list)], want_stats=False)
+            fence()
+            e = time.perf_counter() - t1
+            _, tr_ms, _ = ctx.profile_end()
+            n = args.steps
+            rays = sum(rays_list[i % len(rays_list)] for i in range(n))
+            byts = sum(bytes_list[i % len(bytes_list)] for i in range(n))
+            ach = byts / n / (tr_ms * 1e-3) / 1e9 if tr_ms > 0 else 0.0
+            return {"value": round(rays / e / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(e / n * 1e3, 4),
+                    "kernel_ms": round(tr_ms, 4), "roofline_frac": round(ach / HBM_PEAK_GBS, 5)}
+        ctx.set_coherent_scheduling(False)
+        legs["unhinted"] = leg([U], [my_rays], [my_bytes])
+        legs["unhinted"]["what"] = "same static view, frame-coherent scheduling hints off (a first frame / camera cut runs at this speed)"
+        ctx.set_coherent_scheduling(True)
+        views = [rt.make_uniforms(W, H, cam_pos=(0.0, 0.0, 1.3), rot_deg=(0.0, 1.0 * k, 0.0)) for k in range(max(args.steps, 8))]
+        cnt = [counted(v) for v in views]
+        legs["moving_camera"] = leg(views, [c[0] for c in cnt], [c[3] for c in cnt])
+        legs["moving_camera"]["what"] = "rotY + 1 degree per frame, hints on (tile-level promotion under motion)"
+        for _ in range(3):              # leave the context as the main loop had it: hints of the static view
+            frame.step(U, want_stats=False)
+        fence()
+
+    tot = torch.tensor([float(my_rays), float(my_bytes), elapsed, kernel_ms, float(my_rays_traced)], dtype=torch.float64, device=device)
     if world > 1:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -200,9 +244,10 @@ def main():
         elapsed, kernel_max = float(mx[2]), float(mx[3])
     else:
         kernel_max = kernel_ms
-    total_rays, total_bytes = float(tot[0]), float(tot[1])
+    total_rays, total_bytes, total_traced = float(tot[0]), float(tot[1]), float(tot[4])
 
     if rank == 0:
+        pmc = pmc_traffic(args, world, textured)
         ms_per_step = elapsed / args.steps * 1e3
         value = total_rays * args.steps / elapsed / 1e6
         # roofline of the dominant kernel (traversal): this rank's algorithmic bytes / its average launch duration
@@ -224,16 +269,28 @@ def main():
                                    f"layout {args.layout}, node records {'v2' if encoding == rt.NODES_V2 else 'v1'}, "
                                    + ("textured shading: 3 materials, map_Kd 2048^2 + 1024^2 closed-form RGB8, nearest texel" if textured
                                       else "constant albedo (compute.wgsl:372)"),
-                       "mode": args.mode, "rays_per_frame": int(total_rays), "frames_in_flight": fif, "stripes": "16-row round-robin" if world > 1 else "none",
+                       "mode": args.mode, "rays_per_frame": int(total_rays), "rays_traced_per_frame": int(total_traced), "frames_in_flight": fif, "stripes": "16-row round-robin" if world > 1 else "none",
                        "exchange": ("gather to rank 0" if args.exchange == "root" else "all_gather") if world > 1 else "none"},
             "lbvh_build_ms": {k: round(float(v), 4) for k, v in build.items() if k.startswith("ms_")},
             "lbvh_build_roofline_frac": round(build["algorithmic_bytes"] / (build["ms_total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
             "bvh_broadcast_ms": round(bcast_ms, 3),
             "frame_kernels_ms": round(kernel_ms, 4), "frame_kernels_ms_max_rank": round(kernel_max, 4),
+            # rays that actually enter the tree (k_render's input): `value` also counts one primary ray for every pixel the
+            # cull pass disposes of, as the reference's per-pixel loop casts it (compute.wgsl:268-275)
+            "value_traced": round(total_traced * args.steps / elapsed / 1e6, 2),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(args, world, textured),
-                         "kernel": "k_render", "kernel_ms": round(trav_ms, 4), "algorithmic_bytes_per_launch": int(my_bytes)},
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc.get("k_render_hbm_bytes_per_launch"),
+                         "traffic_source": pmc.get("source"),
+                         "kernel": "k_render", "kernel_ms": round(trav_ms, 4), "algorithmic_bytes_per_launch": int(my_bytes),
+                         "bytes_outside_kernel": int(my_frame_bytes - my_bytes),
+                         # what actually binds the kernel: its working set is cache-resident, fabric traffic is a
+                         # small share of the HBM roof, and the VALU lanes are half idle behind divergent 64-byte gathers
+                         "fabric_frac": (round(pmc["k_render_hbm_bytes_per_launch"] / (trav_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                                         if pmc.get("k_render_hbm_bytes_per_launch") and trav_ms > 0 else None),
+                         "valu_lane_util": pmc.get("k_render_valu_lane_util")},
         }
+        if legs:
+            out["legs"] = legs
         if fif2 is not None:
             out["two_frames_in_flight"] = fif2
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
@@ -254,12 +311,15 @@ def pmc_traffic(args, world, textured):
     try:
         t = json.load(open(path))
     except (OSError, ValueError):
-        return None
+        return {}
     w = t.get("workload", {})
     same = (world == 1 and w.get("scene") == args.scene and w.get("width") == args.width and w.get("height") == args.height
             and w.get("mode") == args.mode and w.get("layout") == args.layout and (args.mode != "pt" or w.get("spp") == args.spp)
             and bool(w.get("textured", False)) == textured)
-    return t.get("k_render_hbm_bytes_per_launch") if same else None
+    if not same:
+        return {}
+    return {"k_render_hbm_bytes_per_launch": t.get("k_render_hbm_bytes_per_launch"), "k_render_valu_lane_util": t.get("k_render_valu_lane_util"),
+            "source": "profiles/traffic.json: " + str(t.get("source", ""))}
 
 
 def cpu_baseline(args, mesh, U, mode, textured, shade):

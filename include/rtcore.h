@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2   /* 2: rt_render_stats.pixels_traced, rt_render_device_noalloc, cache-file trailer */
 
 enum {
   RT_OK = 0,
@@ -198,6 +198,10 @@ typedef struct rt_render_stats {
   uint64_t stack_drops;                          /* only with RT_FLAG_COUNT_WORK */
   float    ms_kernel;                            /* hipEvent time of the frame pipeline (cull + compact + traversal + stats) */
   float    ms_traverse;                          /* hipEvent time of the traversal kernel (k_render) alone */
+  uint64_t pixels_traced;                        /* pixels whose primary ray enters the root box: the ones the traversal kernel
+                                                    traces.  The other pixels - pixels_traced are final after the cull pass and are
+                                                    counted as one primary ray + one root-box test + one pixel each, so that the
+                                                    counters equal the reference's per-pixel loop (compute.wgsl:268-275) */
 } rt_render_stats;
 
 /* Replaces queue.writeBuffer(uniformBuf) + dispatchWorkgroups(ceil(w/16), ceil(h/16)) of

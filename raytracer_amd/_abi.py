@@ -69,7 +69,8 @@ class RenderOpts(C.Structure):
 
 class RenderStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays_primary", "rays_shadow", "rays_bounce", "box_tests", "tri_tests",
-                                          "hit_updates", "pixels", "stack_drops")] + [("ms_kernel", C.c_float), ("ms_traverse", C.c_float)]
+                                          "hit_updates", "pixels", "stack_drops")] + [("ms_kernel", C.c_float), ("ms_traverse", C.c_float),
+                                                                                   ("pixels_traced", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

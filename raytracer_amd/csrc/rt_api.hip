@@ -1013,9 +1013,12 @@ int render_frame(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* op
   }
   if (out) {
     unsigned long long st[8];
+    uint32_t traced = 0;
     HIPCHK(hipMemcpyAsync(st, p.stats, sizeof(st), hipMemcpyDeviceToHost, s));
+    if (p.n_tiles > 0) HIPCHK(hipMemcpyAsync(&traced, p.list_count, sizeof(traced), hipMemcpyDeviceToHost, s));   // k_compact: entries of the pixel list
     HIPCHK(hipStreamSynchronize(s));
     std::memset(out, 0, sizeof(*out));
+    out->pixels_traced = traced;
     out->rays_primary = st[0]; out->rays_shadow = st[1]; out->rays_bounce = st[2];
     out->box_tests = st[3]; out->tri_tests = st[4]; out->hit_updates = st[5]; out->pixels = st[6]; out->stack_drops = st[7];
     if (p.n_tiles > 0) {

@@ -8,7 +8,7 @@ mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 run() {
   name=$1; ctrs=$2; shift 2
-  timeout -s KILL 240 rocprofv3 --pmc $ctrs --output-format csv -d "$out/$name" -- python3 bench.py --no-cpu-baseline --no-fif2 "$@" > "$out/$name.log" 2>&1
+  timeout -s KILL 240 rocprofv3 --pmc $ctrs --output-format csv -d "$out/$name" -- python3 bench.py --no-cpu-baseline --no-fif2 --no-legs "$@" > "$out/$name.log" 2>&1
   rc=$?
   echo "pass $name rc=$rc"
   return $rc

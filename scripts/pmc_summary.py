@@ -40,5 +40,12 @@ for k in sorted(acc):
         traffic[k] = {"fetch_size_kb_raw": fs, "write_size_kb_raw": ws,
                       "hbm_bytes_per_launch": int((2.0 * fs + ws) * 1024)}
         print(f"   => HBM bytes/launch (2*FETCH+WRITE, KB->B) = {traffic[k]['hbm_bytes_per_launch']}")
+    if "SQ_THREAD_CYCLES_VALU" in acc[k] and "SQ_ACTIVE_INST_VALU" in acc[k]:
+        # the `lanes` pass: active lanes per issued VALU instruction / 64 (SQ_ACTIVE_INST_VALU is also collected by the `sq` pass: mean of both)
+        tc = sum(acc[k]["SQ_THREAD_CYCLES_VALU"]) / len(acc[k]["SQ_THREAD_CYCLES_VALU"])
+        ai = sum(acc[k]["SQ_ACTIVE_INST_VALU"]) / len(acc[k]["SQ_ACTIVE_INST_VALU"])
+        if ai > 0:
+            traffic.setdefault(k, {})["valu_lane_util"] = round(tc / (64.0 * ai), 4)
+            print(f"   => VALU lane utilisation = SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU) = {tc / (64.0 * ai):.4f}")
 if len(sys.argv) > 2:
     json.dump(traffic, open(sys.argv[2], "w"), indent=1, sort_keys=True)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything profiles/r1 holds, measured in ONE gpurun call (one box: boxes differ by a few % in k_render time).
+# Everything profiles/<round> holds, measured in ONE gpurun call (one box: boxes differ by a few % in k_render time).
 #   gpurun --timeout 1200 -- 'scripts/refresh_profiles.sh'   then, here:   python scripts/collect_profiles.py
 set -e
 R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/refresh"; rm -rf "$O"; mkdir -p "$O"
@@ -16,7 +16,6 @@ b primary --mode primary
 b aos32 --layout aos32
 b pt16 --mode pt --spp 16 --steps 10
 b s70k_1080p --scene s70k --width 1920 --height 1080 --mode primary
-RTCORE_COHERENT_SCHEDULING=0 b unhinted
 RTCORE_PT_SPLIT=0 b pt16_unsplit --mode pt --spp 16 --steps 10
 echo "[6] cfg 5"; timeout -k 10 500 python bench.py --no-cpu-baseline --scene lattice76 --width 7680 --height 4320 --steps 10 > "$O/bench_cfg5_100Mtri_8k.json" 2> "$O/bench_cfg5.err"
 echo "[7] frag"; b frag_root --mode frag-root --steps 10; b frag_web --mode frag-web --steps 5
