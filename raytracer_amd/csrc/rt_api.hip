@@ -91,9 +91,10 @@ struct rt_ctx {
   uint32_t n_vert = 0, n_nor = 0, n_tri_mesh = 0;
 
   // build scratch
-  DevBuf<uint32_t> bounds_enc, codes, keys_a, keys_b, vals_a, vals_b, hist, tile_status, tile_counter, visit, words;
+  DevBuf<uint32_t> bounds_enc, codes, keys_a, keys_b, vals_a, vals_b, hist, tile_status, tile_counter, words;
   DevBuf<float> bounds_f, centroids;
-  DevBuf<int32_t> child, parent;
+  DevBuf<int32_t> child, parent, span;
+  DevBuf<float4> refit_tables;
   bool built = false;      // codes / order valid
   uint32_t refit_fallbacks = 0;
 
@@ -204,16 +205,16 @@ int finish_bvh(rt_ctx* ctx, bool packed_by_refit = false) {
   HIPCHK(ctx->words.ensure(4));
   b.wide = ctx->wide.p; b.tri_pre = ctx->tri_pre.p;
   uint32_t w[2] = {0, 0};
-  if (packed_by_refit) {   // Karras numbering: root = node 0, internal unless the scene is a single triangle
+  if (packed_by_refit) {   // Karras numbering: root = node 0, internal unless the scene is a single triangle; root_box was fetched by the build
     w[0] = (b.n_tri == 1) ? 0x80000000u : 0u;
   } else {
     HIPCHK(hipMemsetAsync(ctx->words.p, 0, 4 * sizeof(uint32_t), ctx->stream));
     rt_launch_pack_impl(b, ctx->words.p + 0, ctx->words.p + 1, ctx->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(w, ctx->words.p, sizeof(w), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(b.root_box, b.nodes, sizeof(b.root_box), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
   }
-  HIPCHK(hipMemcpyAsync(b.root_box, b.nodes, sizeof(b.root_box), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
   if (w[1] & 2u)
     return ctx->fail(RT_ERR_LIMIT, "a leaf's start/count does not fit the WIDE64 leaf reference (start < 2^" + std::to_string(b.leaf_shift) +
                                    ", count <= " + std::to_string(b.leaf_shift >= 31 ? 1u : (1u << (31 - b.leaf_shift))) + ")");
@@ -266,8 +267,8 @@ extern "C" void rt_destroy(rt_ctx* ctx) {
   ctx->pos.release(); ctx->nor.release(); ctx->vidx.release(); ctx->nidx.release();
   ctx->bounds_enc.release(); ctx->codes.release(); ctx->keys_a.release(); ctx->keys_b.release();
   ctx->vals_a.release(); ctx->vals_b.release(); ctx->hist.release(); ctx->tile_status.release();
-  ctx->tile_counter.release(); ctx->visit.release(); ctx->words.release(); ctx->bounds_f.release(); ctx->centroids.release();
-  ctx->child.release(); ctx->parent.release();
+  ctx->tile_counter.release(); ctx->words.release(); ctx->bounds_f.release(); ctx->centroids.release();
+  ctx->child.release(); ctx->parent.release(); ctx->span.release(); ctx->refit_tables.release();
   ctx->own_nodes.release(); ctx->own_tri_pos.release(); ctx->own_tri_nor.release();
   ctx->wide.release(); ctx->tri_pre.release();
   ctx->texcoords.release(); ctx->tri_uv.release(); ctx->tidx.release(); ctx->matid.release(); ctx->materials.release();
@@ -348,21 +349,20 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
   HIPCHK(ctx->bounds_enc.ensure(rt_bounds_words())); HIPCHK(ctx->bounds_f.ensure(8)); HIPCHK(ctx->centroids.ensure((size_t)T * 3));
   HIPCHK(ctx->codes.ensure(T)); HIPCHK(ctx->keys_a.ensure(T)); HIPCHK(ctx->keys_b.ensure(T));
   HIPCHK(ctx->vals_a.ensure(T)); HIPCHK(ctx->vals_b.ensure(T));
-  HIPCHK(ctx->hist.ensure(4 * 256)); HIPCHK(ctx->tile_status.ensure(rt_sort_status_words(T)));
+  HIPCHK(ctx->hist.ensure(rt_sort_hist_words())); HIPCHK(ctx->tile_status.ensure(rt_sort_status_words(T)));
   HIPCHK(ctx->tile_counter.ensure(4)); HIPCHK(ctx->words.ensure(4));
   HIPCHK(ctx->child.ensure(2 * (size_t)(T > 1 ? T - 1 : 1))); HIPCHK(ctx->parent.ensure(N));
-  HIPCHK(ctx->visit.ensure(T > 1 ? T - 1 : 1));
+  HIPCHK(ctx->span.ensure(T > 1 ? T - 1 : 1)); HIPCHK(ctx->refit_tables.ensure(rt_refit_table_float4s(T)));
   HIPCHK(ctx->own_nodes.ensure((size_t)N * 8)); HIPCHK(ctx->own_tri_pos.ensure((size_t)T * 12));
   HIPCHK(ctx->own_tri_nor.ensure((size_t)T * 12));
   HIPCHK(ctx->wide.ensure((size_t)N * 4)); HIPCHK(ctx->tri_pre.ensure((size_t)T * 3));
-  const int leaf_shift = leaf_shift_for(T);
 
   RtBuildBuffers b;
   b.pos = ctx->pos.p; b.nor = ctx->nor.p; b.vidx = ctx->vidx.p; b.nidx = ctx->nidx.p; b.n_tri = T;
   b.bounds_enc = ctx->bounds_enc.p; b.bounds_f = ctx->bounds_f.p; b.centroids = ctx->centroids.p; b.codes = ctx->codes.p;
   b.keys_a = ctx->keys_a.p; b.keys_b = ctx->keys_b.p; b.vals_a = ctx->vals_a.p; b.vals_b = ctx->vals_b.p;
   b.hist = ctx->hist.p; b.tile_status = ctx->tile_status.p; b.tile_counter = ctx->tile_counter.p;
-  b.err_flag = ctx->words.p + 2; b.child = ctx->child.p; b.parent = ctx->parent.p; b.visit = ctx->visit.p;
+  b.err_flag = ctx->words.p + 2; b.child = ctx->child.p; b.parent = ctx->parent.p; b.span = ctx->span.p; b.refit_tables = ctx->refit_tables.p;
   b.n_sort_tiles = rt_sort_tile_count(T);
   b.texcoords = nullptr; b.tex_idx = nullptr; b.material_ids = nullptr; b.tri_uv = nullptr;
   if (ctx->surface_set) {          // surface records into BVH order by the refit, next to triPos / triNor
@@ -381,27 +381,22 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
   HIPCHK(hipEventRecord(ctx->ev[3], s));
   rt_launch_karras(b, s);
   HIPCHK(hipEventRecord(ctx->ev[4], s));
-  rt_launch_refit(b, ctx->own_nodes.p, ctx->own_tri_pos.p, ctx->own_tri_nor.p, ctx->wide.p, ctx->tri_pre.p, leaf_shift, /*fenced=*/false, v2, s);
+  rt_launch_refit(b, ctx->own_nodes.p, ctx->own_tri_pos.p, ctx->own_tri_nor.p, ctx->wide.p, ctx->tri_pre.p, v2, s);
   HIPCHK(hipEventRecord(ctx->ev[5], s));
   HIPCHK(hipGetLastError());
+  // one read-back for the whole build: the sort's error word and the root record (the frame pipeline's screen-space
+  // cull rectangle is computed on the host from it)
   uint32_t errw = 0;
+  float root_box[8];
   HIPCHK(hipMemcpyAsync(&errw, ctx->words.p + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(root_box, ctx->own_nodes.p, sizeof(root_box), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   if (errw & 1u) return ctx->fail(RT_ERR_INTERNAL, "rt_build_lbvh: radix-sort look-back spin limit expired");
-  if (errw & 8u) {   // the write-through hand-off was caught stale by k_refit_verify: redo with full fences
-    ctx->refit_fallbacks += 1;
-    HIPCHK(hipMemsetAsync(ctx->words.p + 2, 0, sizeof(uint32_t), s));
-    if (T > 1) HIPCHK(hipMemsetAsync(ctx->visit.p, 0, sizeof(uint32_t) * (size_t)(T - 1), s));   // arrival counters (k_karras zeroed them once)
-    rt_launch_refit(b, ctx->own_nodes.p, ctx->own_tri_pos.p, ctx->own_tri_nor.p, ctx->wide.p, ctx->tri_pre.p, leaf_shift, /*fenced=*/true, v2, s);
-    HIPCHK(hipEventRecord(ctx->ev[5], s));
-    HIPCHK(hipMemcpyAsync(&errw, ctx->words.p + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (errw) return ctx->fail(RT_ERR_INTERNAL, "rt_build_lbvh: refit verification failed even with agent-scope fences");
-  }
 
   ctx->bvh = RtBvhDev();
   ctx->bvh.nodes = ctx->own_nodes.p; ctx->bvh.tri_pos = ctx->own_tri_pos.p; ctx->bvh.tri_nor = ctx->own_tri_nor.p;
   ctx->bvh.n_nodes = N; ctx->bvh.n_tri = T; ctx->bvh.owns_interchange = true;
+  std::memcpy(ctx->bvh.root_box, root_box, sizeof(root_box));
   HIPCHK(hipEventRecord(ctx->ev[6], s));
   ctx->tri_uv_n = ctx->surface_set ? T : 0;
   int rc = finish_bvh(ctx, /*packed_by_refit=*/true);

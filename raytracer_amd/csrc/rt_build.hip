@@ -4,13 +4,14 @@
 // web/morton_compute.wgsl, and never dispatches it — F4):
 //   k_bounds*      centroid min/max reduction (order-independent => bit-exact)
 //   k_morton       morton_compute.wgsl:33-69, one thread per triangle
-//   k_sort_*       onesweep LSD radix sort, 4 x 8-bit digits, (key, payload) pairs, STABLE:
-//                  one global histogram pass, then per digit a single pass with
-//                  chained-scan decoupled look-back, wave64 ballot/popcount ranking and an
+//   k_onesweep     onesweep LSD radix sort, 3 x 10-bit digits, (key, payload) pairs, STABLE:
+//                  global digit histograms from k_morton, then per digit a single pass with
+//                  chained-scan decoupled look-back, wave64 ballot/popcount ranking (10 ballots per key) and an
 //                  LDS-staged scatter
 //   k_karras       Karras 2012 radix tree, one thread per internal node, ties broken by index
-//   k_refit        one thread per leaf: emit BVH-ordered triangle buffers + leaf record, then
-//                  climb; the second arrival at a node (atomic counter) unions the children
+//   k_refit_*      one thread per leaf: emit BVH-ordered triangle buffers + leaf record, then climb the nodes inside
+//                  the thread's 256-leaf block through LDS; nodes above the blocks are range queries over leaf boxes
+//                  and sparse tables of block boxes (no hand-off between workgroups inside a launch)
 //   k_pack_*       derive the traversal layout (64-byte two-child records, hoisted edges)
 // All kernels are HBM-bound integer/min-max work: coalesced 4-16 B/lane accesses, LDS staging,
 // no MFMA.
@@ -20,7 +21,10 @@
 namespace {
 
 constexpr int BLK = 256;
-constexpr int RADIX = 256;
+constexpr int RADIX_BITS = 10;                     // 30-bit Morton keys = 3 digits of 10 bits: three onesweep passes
+constexpr int RADIX = 1 << RADIX_BITS;
+constexpr int SORT_PASSES = 3;
+constexpr int DPT = RADIX / BLK;                   // digits owned by a thread: 4 consecutive ones
 constexpr int SORT_KPT = 16;                       // keys per thread
 constexpr int SORT_TILE = BLK * SORT_KPT;          // 4096 keys per tile
 constexpr uint32_t ST_AGG = 1u << 30, ST_INCL = 2u << 30, ST_MASK = (1u << 30) - 1u;
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(384) void k_bounds_final(const uint32_t* __restrict
                                                       uint32_t* __restrict__ hist, uint32_t* __restrict__ tile_counter) {
   __shared__ uint32_t s[6];
   // the sort's global digit histograms and tile tickets start at zero (saves three memset launches)
-  for (int i = threadIdx.x; i < 4 * RADIX; i += 384) hist[i] = 0u;
+  for (int i = threadIdx.x; i < SORT_PASSES * RADIX; i += 384) hist[i] = 0u;
   if (threadIdx.x < 4) tile_counter[threadIdx.x] = 0u;
   const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
   uint32_t v = (k < 3) ? 0xFFFFFFFFu : 0u;
@@ -108,39 +112,36 @@ __global__ __launch_bounds__(384) void k_bounds_final(const uint32_t* __restrict
 }
 
 // ---------------------------------------------------------------- Morton codes
+// Also the sort's global digit histograms (the keys are in registers here: no separate histogram pass over them): one
+// LDS histogram per block and digit position, flushed with one global atomic per non-empty bin.  Few, fat blocks: the flush
+// costs one same-address atomic per block and bin.
 __global__ __launch_bounds__(BLK) void k_morton(const float* __restrict__ centroids,
                                                 uint32_t n_tri, const float* __restrict__ bounds_f,
-                                                uint32_t* __restrict__ codes, uint32_t* __restrict__ keys,
-                                                uint32_t* __restrict__ vals, uint32_t* __restrict__ tile_status, size_t n_status) {
-  // the look-back words of the four sort passes start at zero (their own memset launch otherwise)
+                                                uint32_t* __restrict__ codes, uint32_t* __restrict__ hist,
+                                                uint32_t* __restrict__ tile_status, size_t n_status) {
+  __shared__ uint32_t h[SORT_PASSES][RADIX];
+  for (int i = threadIdx.x; i < SORT_PASSES * RADIX; i += BLK) (&h[0][0])[i] = 0u;
+  // the look-back words of the sort passes start at zero (their own memset launch otherwise)
   for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < n_status; i += (size_t)gridDim.x * BLK) tile_status[i] = 0u;
+  __syncthreads();
   const V3 bmin = v3(bounds_f[0], bounds_f[1], bounds_f[2]), inv = v3(bounds_f[4], bounds_f[5], bounds_f[6]);
   for (uint32_t t = blockIdx.x * BLK + threadIdx.x; t < n_tri; t += gridDim.x * BLK) {
     const V3 ctr = v3(centroids[3 * (size_t)t + 0], centroids[3 * (size_t)t + 1], centroids[3 * (size_t)t + 2]);   // :52, from k_bounds
     V3 nrm = (ctr - bmin) * inv;                                          // :55
     uint32_t code = (expand_bits(quantize10(nrm.x)) << 2) | (expand_bits(quantize10(nrm.y)) << 1) |
                     expand_bits(quantize10(nrm.z));                      // :58-68
-    codes[t] = code; keys[t] = code; vals[t] = t;
-  }
-}
-
-// ---------------------------------------------------------------- onesweep radix sort
-__global__ __launch_bounds__(BLK) void k_sort_hist(const uint32_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ hist) {
-  __shared__ uint32_t h[4][RADIX];
-  for (int i = threadIdx.x; i < 4 * RADIX; i += BLK) (&h[0][0])[i] = 0;
-  __syncthreads();
-  for (uint32_t i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) {
-    uint32_t k = keys[i];
+    codes[t] = code;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) atomicAdd(&h[p][(k >> (8 * p)) & 255u], 1u);
+    for (int p = 0; p < SORT_PASSES; ++p) atomicAdd(&h[p][(code >> (RADIX_BITS * p)) & (RADIX - 1)], 1u);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 4 * RADIX; i += BLK) {
-    uint32_t v = (&h[0][0])[i];
+  for (int i = threadIdx.x; i < SORT_PASSES * RADIX; i += BLK) {
+    const uint32_t v = (&h[0][0])[i];
     if (v) atomicAdd(&hist[i], v);
   }
 }
 
+// ---------------------------------------------------------------- onesweep radix sort
 // block-wide exclusive scan of one value per thread (BLK = 256 = 4 waves)
 RT_DEV uint32_t block_excl_scan(uint32_t v, uint32_t* s_wave /*[4]*/, uint32_t* total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -160,35 +161,47 @@ RT_DEV uint32_t block_excl_scan(uint32_t v, uint32_t* s_wave /*[4]*/, uint32_t* 
   return base + inc - v;
 }
 
-__global__ __launch_bounds__(BLK) void k_sort_scan(uint32_t* hist) {   // 4 blocks: one per digit position
-  __shared__ uint32_t s_wave[BLK / 64];
-  uint32_t* h = hist + blockIdx.x * RADIX;
-  uint32_t v = h[threadIdx.x];
-  uint32_t ex = block_excl_scan(v, s_wave, nullptr);
-  h[threadIdx.x] = ex;
-}
+// One LSD pass over a 10-bit digit.  Thread t owns the four consecutive digits 4t .. 4t+3: their tile counts travel as four
+// look-back words {flag | count} in one 16-byte write-through store, and the digit
+// bases (exclusive scan of the pass's global histogram, which k_morton left as raw counts) are scanned here, per block,
+// instead of by a launch of their own.  FIRST: the payload of key i is i itself, nothing to read.
+#ifdef RT_SORT_TIMELINE   // analysis build only (make EXTRA=-DRT_SORT_TIMELINE): stage clocks of every onesweep tile (tools/sort_timeline.py)
+__device__ unsigned long long g_sort_tl[SORT_PASSES][4096][8];
+#define SORT_STAMP(k) do { if (tid == 0 && tile < 4096u) g_sort_tl[shift / RADIX_BITS][tile][k] = wall_clock64(); } while (0)
+#else
+#define SORT_STAMP(k) do { } while (0)
+#endif
 
-__global__ __launch_bounds__(BLK) void k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool FIRST>
+__global__ __launch_bounds__(BLK, 2)    // 2 blocks per CU (60 KB of LDS each): at most 256 VGPRs
+void k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                   uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                  uint32_t n, int shift, const uint32_t* __restrict__ digit_base,
-                                                  uint32_t* status, uint32_t* tile_counter, uint32_t* err_flag) {
+                                                  uint32_t n, int shift, const uint32_t* __restrict__ hist,
+                                                  uint32_t* status /* [n_tiles + groups][RADIX] */, uint32_t n_tiles, uint32_t status_bytes,
+                                                  int gshift, int use_ticket, uint32_t* tile_counter, uint32_t* err_flag) {
   __shared__ uint32_t s_keys[SORT_TILE];
   __shared__ uint32_t s_vals[SORT_TILE];
-  __shared__ uint32_t s_whist[BLK / 64][RADIX];
-  __shared__ uint32_t s_dstart[RADIX];
-  __shared__ uint32_t s_gbase[RADIX];
+  __shared__ __align__(16) uint32_t s_whist[BLK / 64][RADIX];
+  __shared__ __align__(16) uint32_t s_dstart[RADIX];
+  __shared__ __align__(16) uint32_t s_gbase[RADIX];
+  __shared__ __align__(16) uint32_t s_cnt[RADIX];
   __shared__ uint32_t s_wave[BLK / 64];
   __shared__ uint32_t s_tile;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // tile ids are handed out in start order, so every predecessor tile is already running:
-  // the look-back below cannot wait on a block that has not been scheduled.
-  if (tid == 0) s_tile = atomicAdd(tile_counter, 1u);
-  for (int i = tid; i < (BLK / 64) * RADIX; i += BLK) (&s_whist[0][0])[i] = 0;
+  // Tile ids: handed out in start order when the grid is larger than what the chip holds at once (every predecessor of a
+  // tile is then already running: the look-back cannot wait on a block that was never scheduled); the block index when
+  // every tile is resident anyway (320 same-address ticket atomics spread the tile starts over 4 us).
+  if (use_ticket && tid == 0) s_tile = atomicAdd(tile_counter, 1u);
+  for (int i = tid; i < (BLK / 64) * RADIX / 4; i += BLK) reinterpret_cast<uint4*>(&s_whist[0][0])[i] = make_uint4(0u, 0u, 0u, 0u);
+  reinterpret_cast<uint4*>(s_cnt)[tid] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
-  const uint32_t tile = s_tile;
+  const uint32_t tile = use_ticket ? s_tile : blockIdx.x;
   const uint32_t base = tile * (uint32_t)SORT_TILE;
   const uint32_t wbase = base + (uint32_t)wave * (64 * SORT_KPT);
+  SORT_STAMP(0);
 
   uint32_t key[SORT_KPT], val[SORT_KPT], rank[SORT_KPT];
 #pragma unroll
@@ -196,18 +209,87 @@ __global__ __launch_bounds__(BLK) void k_onesweep(const uint32_t* __restrict__ k
     uint32_t idx = wbase + r * 64 + lane;
     bool valid = idx < n;
     key[r] = valid ? keys_in[idx] : 0xFFFFFFFFu;
-    val[r] = valid ? vals_in[idx] : 0u;
   }
-  // wave-level stable ranking: peers = lanes holding the same digit (8 ballots), rank inside
+  // the digit bases of this pass: exclusive scan of the global histogram (independent of everything below: issued early)
+  const uint4 hcnt = reinterpret_cast<const uint4*>(hist)[tid];
+  // 1. The tile's digit counts, as early as possible: every later tile waits for them (they are what the look-back sums),
+  //    so they are counted with plain LDS atomics and published BEFORE the ranking, not derived from it.
+#pragma unroll
+  for (int r = 0; r < SORT_KPT; ++r)
+    if ((wbase + r * 64 + lane) < n) atomicAdd(&s_cnt[(key[r] >> shift) & (uint32_t)(RADIX - 1)], 1u);
+#pragma unroll
+  for (int r = 0; r < SORT_KPT; ++r) {                         // payloads: needed at the scatter only
+    uint32_t idx = wbase + r * 64 + lane;
+    val[r] = FIRST ? idx : (idx < n ? vals_in[idx] : 0u);
+  }
+  __syncthreads();
+  uint32_t total[DPT];
+  {
+    const uint4 c = reinterpret_cast<const uint4*>(s_cnt)[tid];    // thread t owns digits 4t .. 4t+3
+    total[0] = c.x; total[1] = c.y; total[2] = c.z; total[3] = c.w;
+  }
+  // Look-back words: one u32 per digit = 2-bit flag | 30-bit count, self-validating (a torn 16-byte access is harmless: every
+  // word carries its own flag).  A thread's four digits travel as ONE 16-byte write-through (sc1) store and are read with
+  // 16-byte sc1 loads (half the fabric writes of 8-byte words: the small write-through stores are what the pass waits for).
+  const __amdgpu_buffer_rsrc_t st_rsrc = __builtin_amdgcn_make_buffer_rsrc(status, 0, (int)status_bytes, 0x00020000);
+  const uint32_t my_off = 16u * (uint32_t)tid;              // byte offset of my four words inside a tile's / group's 4 KB row
+  auto publish = [&](uint32_t row, uint32_t f, const uint32_t v[DPT]) {
+    const u32x4 x = {f | v[0], f | v[1], f | v[2], f | v[3]};
+    __builtin_amdgcn_raw_buffer_store_b128(x, st_rsrc, row * (uint32_t)(RADIX * 4) + my_off, 0, 16);      // aux 16 = sc1
+  };
+  auto fetch = [&](uint32_t row) -> uint4 {
+    const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(st_rsrc, row * (uint32_t)(RADIX * 4) + my_off, 0, 16);
+    return make_uint4(x[0], x[1], x[2], x[3]);
+  };
+  publish(tile, ST_AGG, total);
+  constexpr int LBG = 16;                                  // predecessors of my group fetched per round trip
+  constexpr int LB = 16;                                   // group words fetched per round trip
+  const uint32_t grp = tile >> gshift, g0 = grp << gshift;
+  const bool closes_group = ((tile + 1u) & ((1u << gshift) - 1u)) == 0u;
+  uint32_t excl[DPT] = {0u, 0u, 0u, 0u};
+  uint32_t spins = 0;
+  bool fail = false;
+  auto in_group_sum = [&]() {                              // counts of the predecessors p-1 .. g0 of my group: pure sums, any order
+    for (uint32_t p = tile; p > g0 && !fail;) {
+      const uint32_t nb = (p - g0 < (uint32_t)LBG) ? (p - g0) : (uint32_t)LBG;
+      for (;;) {                                           // the whole batch again if any word is not there yet (never a stale register copy)
+        uint4 w[LBG];
+#pragma unroll
+        for (int k = 0; k < LBG; ++k) if ((uint32_t)k < nb) w[k] = fetch(p - 1u - k);
+        uint32_t ready = 3u << 30;
+#pragma unroll
+        for (int k = 0; k < LBG; ++k) if ((uint32_t)k < nb) ready = min(ready, min(min(w[k].x >> 30, w[k].y >> 30), min(w[k].z >> 30, w[k].w >> 30)));
+        if (ready != 0u) {
+#pragma unroll
+          for (int k = 0; k < LBG; ++k)
+            if ((uint32_t)k < nb) { excl[0] += w[k].x & ST_MASK; excl[1] += w[k].y & ST_MASK; excl[2] += w[k].z & ST_MASK; excl[3] += w[k].w & ST_MASK; }
+          break;
+        }
+        if (++spins > SPIN_LIMIT) { atomicOr(err_flag, 1u); fail = true; break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      p -= nb;
+    }
+  };
+  // The tile that closes a group sums its group NOW (its predecessors publish their counts within the first microseconds
+  // of their own run) and publishes the group's sum before it ranks: by the time the other tiles have ranked their keys,
+  // every group word they need is there.  Group 0's sum is already its inclusive prefix.
+  if (closes_group) {
+    in_group_sum();
+    const uint32_t v[DPT] = {excl[0] + total[0], excl[1] + total[1], excl[2] + total[2], excl[3] + total[3]};
+    publish(n_tiles + grp, grp == 0u ? ST_INCL : ST_AGG, v);
+  }
+  SORT_STAMP(1);
+  // 2. wave-level stable ranking: peers = lanes holding the same digit (10 ballots), rank inside
   // the peer group by popcount below the lane; the group leader bumps the wave's digit counter.
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
   for (int r = 0; r < SORT_KPT; ++r) {
     const bool valid = (wbase + r * 64 + lane) < n;
-    const uint32_t d = (key[r] >> shift) & 255u;
+    const uint32_t d = (key[r] >> shift) & (uint32_t)(RADIX - 1);
     unsigned long long peers = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < RADIX_BITS; ++b) {
       const bool bit = (d >> b) & 1u;
       const unsigned long long bal = __ballot(bit);
       peers &= bit ? bal : ~bal;
@@ -222,61 +304,101 @@ __global__ __launch_bounds__(BLK) void k_onesweep(const uint32_t* __restrict__ k
     rank[r] = prev + (uint32_t)__popcll(peers & lt_mask);
   }
   __syncthreads();
-
-  // thread d owns digit d: per-wave exclusive offsets, tile total, look-back
-  uint32_t total = 0;
-  {
-    uint32_t run = 0;
+  {   // per-wave exclusive offsets of my four digits
+    uint32_t run[DPT] = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int w = 0; w < BLK / 64; ++w) { uint32_t c = s_whist[w][tid]; s_whist[w][tid] = run; run += c; }
-    total = run;
-  }
-  uint32_t* my_status = status + (size_t)tile * RADIX + tid;
-  __hip_atomic_store(my_status, (tile == 0 ? ST_INCL : ST_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const uint32_t dstart = block_excl_scan(total, s_wave, nullptr);
-  uint32_t excl = 0;
-  if (tile > 0) {
-    uint32_t p = tile - 1, spins = 0;
-    for (;;) {
-      const uint32_t sw = __hip_atomic_load(status + (size_t)p * RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint32_t f = sw >> 30;
-      if (f == 0) {
-        if (++spins > SPIN_LIMIT) { atomicOr(err_flag, 1u); break; }
-        __builtin_amdgcn_s_sleep(1);
-        continue;
-      }
-      excl += sw & ST_MASK;
-      if (f == 2 || p == 0) break;
-      --p;
+    for (int w = 0; w < BLK / 64; ++w) {
+      uint4* cell = reinterpret_cast<uint4*>(&s_whist[w][DPT * tid]);
+      const uint4 c = *cell;
+      *cell = make_uint4(run[0], run[1], run[2], run[3]);
+      run[0] += c.x; run[1] += c.y; run[2] += c.z; run[3] += c.w;
     }
-    __hip_atomic_store(my_status, ST_INCL | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  s_dstart[tid] = dstart;
-  s_gbase[tid] = digit_base[tid] + excl - dstart;
+  // Grouped look-back.  A chained walk (one predecessor per step, stop at the first inclusive prefix) takes ~25 dependent
+  // hops when all 320 tiles of a 1.3 M-key pass run at once: 11 of a pass's 30 us.  Here tiles form groups of G = 2^gshift:
+  //   1. every tile publishes its counts (AGG) before it ranks (above);
+  //   2. the last tile of a group sums its group's counts and publishes the group's sum (AGG; group 0: INCL) in a second
+  //      array, also before it ranks (above);
+  //   3. after ranking, every tile sums the counts of the predecessors INSIDE its group (all fetched at once) and walks back
+  //      over the GROUP words (16 per round trip, in order, until an INCL);
+  //   4. the last tile of a group then publishes the group's inclusive prefix (INCL).
+  // A tile only ever waits for tiles with smaller ids (already running).
+  const uint32_t tsum = total[0] + total[1] + total[2] + total[3];
+  const uint32_t dstart0 = block_excl_scan(tsum, s_wave, nullptr);
+  const uint32_t dbase0 = block_excl_scan(hcnt.x + hcnt.y + hcnt.z + hcnt.w, s_wave, nullptr);
+  SORT_STAMP(2);
+  if (!closes_group) in_group_sum();                       // (their predecessors published before their own ranking: ready by now)
+  if (grp > 0u && !fail) {
+    // group words in order, nearest first, until an inclusive prefix (group 0's is one); per digit word, since the four
+    // words of a row may become visible one after the other
+    uint32_t pos[DPT] = {grp, grp, grp, grp};              // next group to consume is pos - 1; 0 = done
+    for (;;) {
+      const uint32_t top = max(max(pos[0], pos[1]), max(pos[2], pos[3]));
+      if (top == 0u) break;
+      uint4 w[LB];
+#pragma unroll
+      for (int k = 0; k < LB; ++k) if ((uint32_t)k < top) w[k] = fetch(n_tiles + top - 1u - k);
+      bool progressed = false;
+#pragma unroll
+      for (int q = 0; q < DPT; ++q) {
+        bool stop = false;
+#pragma unroll
+        for (int k = 0; k < LB; ++k) {
+          const uint32_t gidx = top - 1u - (uint32_t)k;     // the group word k holds
+          if (!stop && (uint32_t)k < top && pos[q] != 0u && gidx == pos[q] - 1u) {
+            const uint32_t x = q == 0 ? w[k].x : q == 1 ? w[k].y : q == 2 ? w[k].z : w[k].w, f = x >> 30;
+            if (f == 0u) stop = true;
+            else { excl[q] += x & ST_MASK; progressed = true; pos[q] = (f == 2u) ? 0u : pos[q] - 1u; }
+          }
+        }
+      }
+      if (!progressed) {
+        if (++spins > SPIN_LIMIT) { atomicOr(err_flag, 1u); break; }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    if (closes_group) {
+      const uint32_t v[DPT] = {excl[0] + total[0], excl[1] + total[1], excl[2] + total[2], excl[3] + total[3]};
+      publish(n_tiles + grp, ST_INCL, v);
+    }
+  }
+  {
+    const uint32_t hc[DPT] = {hcnt.x, hcnt.y, hcnt.z, hcnt.w};
+    uint32_t ds = dstart0, db = dbase0;
+#pragma unroll
+    for (int q = 0; q < DPT; ++q) {
+      s_dstart[DPT * tid + q] = ds;
+      s_gbase[DPT * tid + q] = db + excl[q] - ds;
+      ds += total[q]; db += hc[q];
+    }
+  }
   __syncthreads();
+  SORT_STAMP(3);
 
   // LDS-staged scatter: tile-local sorted order first, then coalesced runs to HBM
 #pragma unroll
   for (int r = 0; r < SORT_KPT; ++r) {
     if ((wbase + r * 64 + lane) < n) {
-      const uint32_t d = (key[r] >> shift) & 255u;
+      const uint32_t d = (key[r] >> shift) & (uint32_t)(RADIX - 1);
       const uint32_t pos = s_dstart[d] + s_whist[wave][d] + rank[r];
       s_keys[pos] = key[r];
       s_vals[pos] = val[r];
     }
   }
   __syncthreads();
+  SORT_STAMP(4);
   const uint32_t cnt = (n - base < (uint32_t)SORT_TILE) ? (n - base) : (uint32_t)SORT_TILE;
 #pragma unroll
   for (int k = 0; k < SORT_KPT; ++k) {
     const uint32_t i = tid + k * BLK;
     if (i < cnt) {
       const uint32_t kk = s_keys[i];
-      const uint32_t out = s_gbase[(kk >> shift) & 255u] + i;
+      const uint32_t out = s_gbase[(kk >> shift) & (uint32_t)(RADIX - 1)] + i;
       keys_out[out] = kk;
       vals_out[out] = s_vals[i];
     }
   }
+  SORT_STAMP(5);
 }
 
 // ---------------------------------------------------------------- Karras radix tree
@@ -290,12 +412,11 @@ RT_DEV int kdelta(const uint32_t* __restrict__ k, int n, int i, uint32_t ki, int
 
 __global__ __launch_bounds__(BLK) void k_karras(const uint32_t* __restrict__ k, uint32_t n_tri,
                                                 int32_t* __restrict__ child, int32_t* __restrict__ parent,
-                                                uint32_t* __restrict__ visit) {
+                                                int32_t* __restrict__ span) {
   const int n = (int)n_tri;
   const int i = blockIdx.x * BLK + threadIdx.x;
   if (i == 0) parent[0] = -1;
   if (i >= n - 1) return;
-  visit[i] = 0u;                                   // the refit's arrival counter of this node (its own memset launch otherwise)
   const uint32_t ki = k[i];
   const int d = (kdelta(k, n, i, ki, i + 1) - kdelta(k, n, i, ki, i - 1)) > 0 ? 1 : -1;
   const int dmin = kdelta(k, n, i, ki, i - d);
@@ -317,82 +438,65 @@ __global__ __launch_bounds__(BLK) void k_karras(const uint32_t* __restrict__ k, 
   const int c0 = (lo == gamma) ? (n - 1) + gamma : gamma;
   const int c1 = (hi == gamma + 1) ? (n - 1) + gamma + 1 : gamma + 1;
   child[2 * (size_t)i + 0] = c0; child[2 * (size_t)i + 1] = c1;
-  // bit 30: this node's leaf range [lo, hi] lies inside one 256-leaf block of k_refit (block-local climb)
+  span[i] = j;                                     // the other end of the node's leaf range [min(i, j), max(i, j)] (one end is i itself)
+  // bit 30: this node's leaf range [lo, hi] lies inside one 256-leaf block of the refit (block-local climb)
   const int link = i | (((lo >> 8) == (hi >> 8)) ? (1 << 30) : 0);
   parent[c0] = link; parent[c1] = link;
 }
 
 // ---------------------------------------------------------------- leaves + bottom-up refit
-// Node records are handed from the first arrival at a parent to the second one, which may run
-// on another CU / XCD (L1 per CU, L2 per XCD are not coherent).  Two forms:
-//   FENCED = false (default): every record is written with 8-byte agent-scope (sc1, write-
-//     through) stores, drained with s_waitcnt vmcnt(0) before the arrival counter is bumped;
-//     the second arrival reads the sibling with 8-byte agent-scope (sc1) loads.  No L2
-//     write-back / L1 invalidate per hand-off (MI355X_MICROARCH.md "Valid forms", row 1).
-//     k_refit_verify re-derives every internal box from its children afterwards; on any
-//     mismatch the host re-runs the FENCED form.
-//   FENCED = true: plain stores + __threadfence() (release / acquire at agent scope) around
-//     the counter: the textbook form, ~80x slower here (buffer_wbl2 + buffer_inv per arrival).
-RT_DEV unsigned long long pack2f(float a, float b) {
-  return (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
-}
-// through == false: the record is only read by later kernels (its parent is block-local, or it is the root): plain stores,
-// which L2 merges into full lines instead of four 8-byte write-throughs.
-template <bool FENCED>
-RT_DEV void store_node(float* nodes, int idx, V3 mn, float a, V3 mx, float b, bool through = true) {
-  if (FENCED || !through) {
-    float4* nd = reinterpret_cast<float4*>(nodes) + 2 * (size_t)idx;
-    nd[0] = make_float4(mn.x, mn.y, mn.z, a);
-    nd[1] = make_float4(mx.x, mx.y, mx.z, b);
-  } else {
-    unsigned long long* q = reinterpret_cast<unsigned long long*>(nodes) + 4 * (size_t)idx;
-    __hip_atomic_store(q + 0, pack2f(mn.x, mn.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(q + 1, pack2f(mn.z, a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(q + 2, pack2f(mx.x, mx.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(q + 3, pack2f(mx.z, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-template <bool FENCED>
-RT_DEV void load_box(const float* nodes, int idx, V3& mn, V3& mx) {
-  if (FENCED) {
-    const float4* nd = reinterpret_cast<const float4*>(nodes) + 2 * (size_t)idx;
-    const float4 s0 = nd[0], s1 = nd[1];
-    mn = xyz(s0); mx = xyz(s1);
-  } else {
-    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(nodes) + 4 * (size_t)idx;
-    const unsigned long long w0 = __hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long w1 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long w2 = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long w3 = __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    mn = v3(__uint_as_float((uint32_t)w0), __uint_as_float((uint32_t)(w0 >> 32)), __uint_as_float((uint32_t)w1));
-    mx = v3(__uint_as_float((uint32_t)w2), __uint_as_float((uint32_t)(w2 >> 32)), __uint_as_float((uint32_t)w3));
-  }
-}
-
-// Block-local climb.  Block b owns sorted leaves [256 b, 256 b + 255].  k_karras marks a parent link with PARENT_LOCAL
-// when the parent's whole leaf range lies inside one such block; since an internal node's index is one end of its own
-// range, both the node and its two children then belong to that block.  For those nodes the hand-off (arrival counter +
-// sibling box) goes through LDS — no global atomic, no write-through wait — and only the nodes whose range crosses a block
-// boundary (about 1 in 128) take the global path described above.  Every record is still written to HBM (interchange
-// `nodes`, traversal `wide`), the global path reads a locally finished sibling from there.
+// No hand-off between workgroups inside a launch.  Node i of the Karras tree covers the contiguous leaf range
+// [lo, hi] of the sorted order, and min / max are exact and order-independent, so a node's box is a RANGE query over the
+// leaf boxes: nothing has to wait for its children.  Three launches, data crossing between them only at kernel boundaries:
+//   k_refit_local   one thread per leaf: BVH-order triangle records, leaf record, then the climb through the nodes whose
+//                   range lies inside the thread's 256-leaf block (k_karras marks them; ~127 of 128 nodes), handing off
+//                   through LDS; the block's own box goes to block_box[]
+//   k_refit_tables  per super-block of 256 blocks (65 536 leaves): sparse table (9 levels) over its block boxes
+//   k_refit_spans   the nodes whose range crosses a block boundary, one wavefront each: the box of a child is read if
+//                   the child is block-local, else folded from the <= 255 leaf boxes at either ragged end of its range,
+//                   <= 4 sparse-table entries and the boxes of whole super-blocks in between
+// (Before: the ~1 % of nodes above the blocks were handed from CU to CU with write-through stores, an atomic counter and
+// sc1 loads per level - a ~70 us latency chain over the top ~12 levels with the chip nearly idle, 2.7x the traffic,
+// and a verify pass + fenced fallback to guard it.)
 constexpr int PARENT_LOCAL = 1 << 30;
 constexpr int PARENT_MASK = PARENT_LOCAL - 1;
 static_assert(BLK == 256, "k_karras marks block-local nodes with (lo >> 8) == (hi >> 8)");
+constexpr int SUPER = 256;                 // blocks per super-block
+constexpr int ST_LEVELS = 9;               // 2^0 .. 2^8 blocks
+constexpr float BOX_INF = __builtin_inff();
 
-template <bool FENCED>
-__global__ __launch_bounds__(BLK) void k_refit(const float* __restrict__ pos, const float* __restrict__ nor,
-                                               const uint32_t* __restrict__ vidx, const uint32_t* __restrict__ nidx,
-                                               const uint32_t* __restrict__ order, uint32_t n_tri,
-                                               const int32_t* __restrict__ child, const int32_t* __restrict__ parent,
-                                               uint32_t* visit, float* nodes, float* __restrict__ tri_pos,
-                                               float* __restrict__ tri_nor, float4* __restrict__ wide, float4* __restrict__ tri_pre,
-                                               const float* __restrict__ texcoords, const uint32_t* __restrict__ tex_idx,
-                                               const int32_t* __restrict__ material_ids, float4* __restrict__ tri_uv,
-                                               int leaf_shift, bool v2) {
+RT_DEV void store_node(float* nodes, int idx, V3 mn, float a, V3 mx, float b) {
+  float4* nd = reinterpret_cast<float4*>(nodes) + 2 * (size_t)idx;
+  nd[0] = make_float4(mn.x, mn.y, mn.z, a);
+  nd[1] = make_float4(mx.x, mx.y, mx.z, b);
+}
+RT_DEV V3 min3(V3 a, V3 b) { return v3(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)); }
+RT_DEV V3 max3(V3 a, V3 b) { return v3(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)); }
+RT_DEV float wave_min_f(float v) { for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
+RT_DEV float wave_max_f(float v) { for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
+// 64-byte two-child record of node `par` (rt_internal.h), the statements of k_pack_wide
+RT_DEV void store_wide(float4* wide, int par, int c0, int c1, int first_leaf, V3 a_mn, V3 a_mx, V3 b_mn, V3 b_mx) {
+  const uint32_t r0 = (c0 >= first_leaf) ? (0x80000000u | (uint32_t)(c0 - first_leaf)) : (uint32_t)c0;
+  const uint32_t r1 = (c1 >= first_leaf) ? (0x80000000u | (uint32_t)(c1 - first_leaf)) : (uint32_t)c1;
+  wide[4 * (size_t)par + 0] = make_float4(a_mn.x, a_mn.y, a_mn.z, __uint_as_float(r0));
+  wide[4 * (size_t)par + 1] = make_float4(a_mx.x, a_mx.y, a_mx.z, __uint_as_float(r1));
+  wide[4 * (size_t)par + 2] = make_float4(b_mn.x, b_mn.y, b_mn.z, 0.0f);
+  wide[4 * (size_t)par + 3] = make_float4(b_mx.x, b_mx.y, b_mx.z, 0.0f);
+}
+
+__global__ __launch_bounds__(BLK) void k_refit_local(const float* __restrict__ pos, const float* __restrict__ nor,
+                                                     const uint32_t* __restrict__ vidx, const uint32_t* __restrict__ nidx,
+                                                     const uint32_t* __restrict__ order, uint32_t n_tri,
+                                                     const int32_t* __restrict__ child, const int32_t* __restrict__ parent,
+                                                     float* __restrict__ nodes, float* __restrict__ tri_pos,
+                                                     float* __restrict__ tri_nor, float4* __restrict__ wide, float4* __restrict__ tri_pre,
+                                                     const float* __restrict__ texcoords, const uint32_t* __restrict__ tex_idx,
+                                                     const int32_t* __restrict__ material_ids, float4* __restrict__ tri_uv,
+                                                     float4* __restrict__ mini_box, float4* __restrict__ chunk_box, bool v2) {
   __shared__ float s_box[2 * BLK][6];      // [0, BLK): this block's leaves, [BLK, 2 BLK): internal nodes with index in the block's range
   __shared__ uint32_t s_visit[BLK];        // arrival counters of the block-local internal nodes
   __shared__ int s_child[BLK][2];          // links of the internal nodes with index in the block's range, read once, coalesced:
-  __shared__ int s_parent[BLK];            // the local climb then has no dependent global load per level
+  __shared__ int s_parent[BLK];            // the climb then has no dependent global load per level
   s_visit[threadIdx.x] = 0u;
   const uint32_t j = blockIdx.x * BLK + threadIdx.x;
   if (j + 1 < n_tri) {
@@ -401,109 +505,233 @@ __global__ __launch_bounds__(BLK) void k_refit(const float* __restrict__ pos, co
     s_parent[threadIdx.x] = parent[j];
   }
   __syncthreads();
-  if (j >= n_tri) return;
   const int first_leaf = (int)n_tri - 1;   // leaf j is node (T-1)+j, one triangle, start = j
-  const uint32_t ti = order[j];
-  V3 p[3];
-  float4* tp = reinterpret_cast<float4*>(tri_pos) + (size_t)j * 3;
-  float4* tn = reinterpret_cast<float4*>(tri_nor) + (size_t)j * 3;
+  V3 mn = v3(BOX_INF, BOX_INF, BOX_INF), mx = v3(-BOX_INF, -BOX_INF, -BOX_INF);
+  const bool valid = j < n_tri;
+  int pe = -1;
+  if (valid) {
+    const uint32_t ti = order[j];
+    V3 p[3];
+    float4* tp = reinterpret_cast<float4*>(tri_pos) + (size_t)j * 3;
+    float4* tn = reinterpret_cast<float4*>(tri_nor) + (size_t)j * 3;
 #pragma unroll
-  for (int v = 0; v < 3; ++v) {                     // web/script.js:530-545
-    p[v] = load_vtx(pos, vidx[3 * (size_t)ti + v]);
-    V3 nn = load_vtx(nor, nidx[3 * (size_t)ti + v]);
-    tp[v] = make_float4(p[v].x, p[v].y, p[v].z, 0.0f);
-    tn[v] = make_float4(nn.x, nn.y, nn.z, 0.0f);
+    for (int v = 0; v < 3; ++v) {                     // web/script.js:530-545
+      p[v] = load_vtx(pos, vidx[3 * (size_t)ti + v]);
+      V3 nn = load_vtx(nor, nidx[3 * (size_t)ti + v]);
+      tp[v] = make_float4(p[v].x, p[v].y, p[v].z, 0.0f);
+      tn[v] = make_float4(nn.x, nn.y, nn.z, 0.0f);
+    }
+    {                                                  // traversal layout of the triangle, the statements of k_pack_tris
+      const V3 e1 = p[1] - p[0], e2 = p[2] - p[0];
+      const V3 ng = cross3(e1, e2);
+      tri_pre[3 * (size_t)j + 0] = make_float4(p[0].x, p[0].y, p[0].z, ng.x);
+      tri_pre[3 * (size_t)j + 1] = make_float4(e1.x, e1.y, e1.z, ng.y);
+      tri_pre[3 * (size_t)j + 2] = make_float4(e2.x, e2.y, e2.z, ng.z);
+    }
+    if (texcoords) {                                   // surface record (rtcore.h "material / texture shading"), as k_gather_uv
+      const float2* tc = reinterpret_cast<const float2*>(texcoords);
+      const float2 a = tc[tex_idx[3 * (size_t)ti + 0]], b = tc[tex_idx[3 * (size_t)ti + 1]], c = tc[tex_idx[3 * (size_t)ti + 2]];
+      const int32_t m = material_ids ? material_ids[ti] : -1;
+      tri_uv[2 * (size_t)j + 0] = make_float4(a.x, a.y, b.x, b.y);
+      tri_uv[2 * (size_t)j + 1] = make_float4(c.x, c.y, __uint_as_float((uint32_t)m), 0.0f);
+    }
+    // true triangle bounds (web/script.js:309-316)
+    mn = v3(fminf(fminf(p[0].x, p[1].x), p[2].x), fminf(fminf(p[0].y, p[1].y), p[2].y), fminf(fminf(p[0].z, p[1].z), p[2].z));
+    mx = v3(fmaxf(fmaxf(p[0].x, p[1].x), p[2].x), fmaxf(fmaxf(p[0].y, p[1].y), p[2].y), fmaxf(fmaxf(p[0].z, p[1].z), p[2].z));
+    pe = parent[first_leaf + (int)j];                  // link to the parent of the leaf
+    store_node(nodes, first_leaf + (int)j, mn, enc_index(v2, j), mx, enc_leaf_b(v2, 1u));   // A = tri_start, B = -count (script.js:348,554,558)
   }
-  {                                                  // traversal layout of the triangle, the statements of k_pack_tris
-    const V3 e1 = p[1] - p[0], e2 = p[2] - p[0];
-    const V3 ng = cross3(e1, e2);
-    tri_pre[3 * (size_t)j + 0] = make_float4(p[0].x, p[0].y, p[0].z, ng.x);
-    tri_pre[3 * (size_t)j + 1] = make_float4(e1.x, e1.y, e1.z, ng.y);
-    tri_pre[3 * (size_t)j + 2] = make_float4(e2.x, e2.y, e2.z, ng.z);
+  {   // boxes of aligned groups of 16 and 64 leaves (the valid ones), from one xor butterfly: the ragged ends of the ranges in k_refit_spans
+    const int lane = threadIdx.x & 63;
+    V3 a = mn, b = mx;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { a = min3(a, v3(__shfl_xor(a.x, o), __shfl_xor(a.y, o), __shfl_xor(a.z, o))); b = max3(b, v3(__shfl_xor(b.x, o), __shfl_xor(b.y, o), __shfl_xor(b.z, o))); }
+    if ((lane & 15) == 0) {
+      float4* q = mini_box + 2 * ((size_t)blockIdx.x * (BLK / 16) + (threadIdx.x >> 4));
+      q[0] = make_float4(a.x, a.y, a.z, 0.0f); q[1] = make_float4(b.x, b.y, b.z, 0.0f);
+    }
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) { a = min3(a, v3(__shfl_xor(a.x, o), __shfl_xor(a.y, o), __shfl_xor(a.z, o))); b = max3(b, v3(__shfl_xor(b.x, o), __shfl_xor(b.y, o), __shfl_xor(b.z, o))); }
+    if (lane == 0) {
+      float4* q = chunk_box + 2 * ((size_t)blockIdx.x * (BLK / 64) + (threadIdx.x >> 6));
+      q[0] = make_float4(a.x, a.y, a.z, 0.0f); q[1] = make_float4(b.x, b.y, b.z, 0.0f);
+    }
   }
-  if (texcoords) {                                   // surface record (rtcore.h "material / texture shading"), as k_gather_uv
-    const float2* tc = reinterpret_cast<const float2*>(texcoords);
-    const float2 a = tc[tex_idx[3 * (size_t)ti + 0]], b = tc[tex_idx[3 * (size_t)ti + 1]], c = tc[tex_idx[3 * (size_t)ti + 2]];
-    const int32_t m = material_ids ? material_ids[ti] : -1;
-    tri_uv[2 * (size_t)j + 0] = make_float4(a.x, a.y, b.x, b.y);
-    tri_uv[2 * (size_t)j + 1] = make_float4(c.x, c.y, __uint_as_float((uint32_t)m), 0.0f);
-  }
-  // true triangle bounds (web/script.js:309-316)
-  V3 mn = v3(fminf(fminf(p[0].x, p[1].x), p[2].x), fminf(fminf(p[0].y, p[1].y), p[2].y), fminf(fminf(p[0].z, p[1].z), p[2].z));
-  V3 mx = v3(fmaxf(fmaxf(p[0].x, p[1].x), p[2].x), fmaxf(fmaxf(p[0].y, p[1].y), p[2].y), fmaxf(fmaxf(p[0].z, p[1].z), p[2].z));
+  // The climb itself touches LDS only: boxes and arrival counters.  The records of the nodes it finishes are written
+  // afterwards, thread t = internal node (block start + t): consecutive threads, consecutive 32- and 64-byte records.
   int cur = first_leaf + (int)j;
-  int cur_slot = (int)threadIdx.x;                   // LDS slot of `cur`
-  int pe = parent[cur];                              // link to the parent of `cur`
-  store_node<FENCED>(nodes, cur, mn, enc_index(v2, j), mx, enc_leaf_b(v2, 1u),   // A = tri_start, B = -count (script.js:348,554,558)
-                     pe >= 0 && !(pe & PARENT_LOCAL));
-  for (;;) {
-    if (pe < 0) break;
-    const bool local = (pe & PARENT_LOCAL) != 0;
+  int cur_slot = (int)threadIdx.x;                     // LDS slot of `cur`
+  {
+    float* sb = s_box[cur_slot];
+    sb[0] = mn.x; sb[1] = mn.y; sb[2] = mn.z; sb[3] = mx.x; sb[4] = mx.y; sb[5] = mx.z;
+  }
+  while (pe >= 0 && (pe & PARENT_LOCAL)) {             // a parent whose range leaves the block: k_refit_spans
     const int par = pe & PARENT_MASK;
-    uint32_t arrived;
-    int gc0 = 0, gc1 = 0, gpe = -1;
-    if (!local) {                                      // the global path's links do not depend on who arrives second: issue the loads
-      const int2 c = reinterpret_cast<const int2*>(child)[par];   // before the wait + atomic instead of two more round trips after them
-      gc0 = c.x; gc1 = c.y; gpe = parent[par];
-    }
-    if (local) {
-      float* sb = s_box[cur_slot];
-      sb[0] = mn.x; sb[1] = mn.y; sb[2] = mn.z; sb[3] = mx.x; sb[4] = mx.y; sb[5] = mx.z;
-      __threadfence_block();                           // the box is in LDS before the counter moves (one LDS, in-order)
-      arrived = atomicAdd(&s_visit[par & (BLK - 1)], 1u);
-    } else {
-      if (FENCED) __threadfence();                     // release this subtree's records (agent scope)
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through stores have left this CU
-      arrived = atomicAdd(&visit[par], 1u);
-    }
+    __threadfence_block();                             // the box is in LDS before the counter moves (one LDS, in-order)
+    const uint32_t arrived = atomicAdd(&s_visit[par & (BLK - 1)], 1u);
     if (arrived == 0) break;                           // the sibling's thread will finish this node
-    const int c0 = local ? s_child[par & (BLK - 1)][0] : gc0;
-    const int c1 = local ? s_child[par & (BLK - 1)][1] : gc1;
+    const int c0 = s_child[par & (BLK - 1)][0], c1 = s_child[par & (BLK - 1)][1];
     const int sib = (c0 == cur) ? c1 : c0;
-    V3 smn, smx;
-    if (local) {
-      __threadfence_block();
-      const int sslot = (sib >= first_leaf) ? ((sib - first_leaf) & (BLK - 1)) : (BLK + (sib & (BLK - 1)));
-      const float* sb = s_box[sslot];
-      smn = v3(sb[0], sb[1], sb[2]); smx = v3(sb[3], sb[4], sb[5]);
-    } else {
-      if (FENCED) __threadfence();                     // acquire the sibling's record
-      load_box<FENCED>(nodes, sib, smn, smx);
-    }
-    {                                                  // 64-byte two-child record of `par`, the statements of k_pack_wide
-      const bool cur0 = (c0 == cur);
-      const V3 a_mn = cur0 ? mn : smn, a_mx = cur0 ? mx : smx, b_mn = cur0 ? smn : mn, b_mx = cur0 ? smx : mx;
-      const uint32_t r0 = (c0 >= first_leaf) ? (0x80000000u | (uint32_t)(c0 - first_leaf)) : (uint32_t)c0;
-      const uint32_t r1 = (c1 >= first_leaf) ? (0x80000000u | (uint32_t)(c1 - first_leaf)) : (uint32_t)c1;
-      wide[4 * (size_t)par + 0] = make_float4(a_mn.x, a_mn.y, a_mn.z, __uint_as_float(r0));
-      wide[4 * (size_t)par + 1] = make_float4(a_mx.x, a_mx.y, a_mx.z, __uint_as_float(r1));
-      wide[4 * (size_t)par + 2] = make_float4(b_mn.x, b_mn.y, b_mn.z, 0.0f);
-      wide[4 * (size_t)par + 3] = make_float4(b_mx.x, b_mx.y, b_mx.z, 0.0f);
-    }
-    mn = v3(fminf(mn.x, smn.x), fminf(mn.y, smn.y), fminf(mn.z, smn.z));
-    mx = v3(fmaxf(mx.x, smx.x), fmaxf(mx.y, smx.y), fmaxf(mx.z, smx.z));
-    pe = local ? s_parent[par & (BLK - 1)] : gpe;
-    store_node<FENCED>(nodes, par, mn, enc_index(v2, (uint32_t)c0), mx, enc_index(v2, (uint32_t)c1),   // v1: indices as f32 values (F11)
-                       pe >= 0 && !(pe & PARENT_LOCAL));
+    __threadfence_block();
+    const int sslot = (sib >= first_leaf) ? ((sib - first_leaf) & (BLK - 1)) : (BLK + (sib & (BLK - 1)));
+    const float* ss = s_box[sslot];
+    mn = min3(mn, v3(ss[0], ss[1], ss[2])); mx = max3(mx, v3(ss[3], ss[4], ss[5]));
+    pe = s_parent[par & (BLK - 1)];
     cur = par;
-    cur_slot = BLK + (par & (BLK - 1));              // only meaningful while the climb stays local (ranges nest)
+    cur_slot = BLK + (par & (BLK - 1));
+    float* sb = s_box[cur_slot];
+    sb[0] = mn.x; sb[1] = mn.y; sb[2] = mn.z; sb[3] = mx.x; sb[4] = mx.y; sb[5] = mx.z;
+  }
+  __syncthreads();
+  if (j + 1 < n_tri && s_visit[threadIdx.x] == 2u) {   // internal node j was finished here: both children are in LDS
+    const int c0 = s_child[threadIdx.x][0], c1 = s_child[threadIdx.x][1];
+    const float* a = s_box[(c0 >= first_leaf) ? ((c0 - first_leaf) & (BLK - 1)) : (BLK + (c0 & (BLK - 1)))];
+    const float* b = s_box[(c1 >= first_leaf) ? ((c1 - first_leaf) & (BLK - 1)) : (BLK + (c1 & (BLK - 1)))];
+    const float* m = s_box[BLK + threadIdx.x];
+    store_wide(wide, (int)j, c0, c1, first_leaf, v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]), v3(b[0], b[1], b[2]), v3(b[3], b[4], b[5]));
+    store_node(nodes, (int)j, v3(m[0], m[1], m[2]), enc_index(v2, (uint32_t)c0), v3(m[3], m[4], m[5]), enc_index(v2, (uint32_t)c1));   // v1: indices as f32 values (F11)
   }
 }
 
-// every internal box must equal the union of its children's boxes, every slot must be filled
-__global__ __launch_bounds__(BLK) void k_refit_verify(const float* __restrict__ nodes, uint32_t n_tri,
-                                                      const int32_t* __restrict__ child, const uint32_t* __restrict__ visit,
-                                                      uint32_t* err, bool v2) {
-  const uint32_t i = blockIdx.x * BLK + threadIdx.x;
-  if (i + 1 >= n_tri) return;
-  const float4* nd = reinterpret_cast<const float4*>(nodes);
-  const int c0 = child[2 * (size_t)i + 0], c1 = child[2 * (size_t)i + 1];
-  const float4 a = nd[2 * (size_t)i], b = nd[2 * (size_t)i + 1];
-  const float4 a0 = nd[2 * (size_t)c0], b0 = nd[2 * (size_t)c0 + 1], a1 = nd[2 * (size_t)c1], b1 = nd[2 * (size_t)c1 + 1];
-  bool ok = !dec_is_leaf(v2, b.w) && (dec_index(v2, a.w) == c0) && (dec_index(v2, b.w) == c1);
-  ok = ok && a.x == fminf(a0.x, a1.x) && a.y == fminf(a0.y, a1.y) && a.z == fminf(a0.z, a1.z);
-  ok = ok && b.x == fmaxf(b0.x, b1.x) && b.y == fmaxf(b0.y, b1.y) && b.z == fmaxf(b0.z, b1.z);
-  if (!ok) atomicOr(err, 8u);
+// Sparse table over the boxes of one super-block's 256 blocks: st[(s * 9 + k) * 256 + x] = box of blocks [x, x + 2^k) of
+// super-block s (entries reaching past block 255 are never queried); missing blocks count as empty boxes.
+__global__ __launch_bounds__(SUPER) void k_refit_tables(const float4* __restrict__ chunk_box, uint32_t n_chunks, uint32_t n_blocks,
+                                                        float4* __restrict__ st, float4* __restrict__ super_box) {
+  __shared__ float s_lvl[2][SUPER][6];
+  const int t = threadIdx.x;
+  const uint32_t s = blockIdx.x, b = s * SUPER + (uint32_t)t;
+  V3 mn = v3(BOX_INF, BOX_INF, BOX_INF), mx = v3(-BOX_INF, -BOX_INF, -BOX_INF);
+  if (b < n_blocks)
+    for (uint32_t q = 4u * b; q < 4u * b + 4u && q < n_chunks; ++q) { mn = min3(mn, xyz(chunk_box[2 * (size_t)q])); mx = max3(mx, xyz(chunk_box[2 * (size_t)q + 1])); }
+  int cur = 0;
+  for (int k = 0; k < ST_LEVELS; ++k) {
+    float4* out = st + (((size_t)s * ST_LEVELS + k) * SUPER + t) * 2;
+    out[0] = make_float4(mn.x, mn.y, mn.z, 0.0f); out[1] = make_float4(mx.x, mx.y, mx.z, 0.0f);
+    if (k == ST_LEVELS - 1) break;
+    float* me = s_lvl[cur][t];
+    me[0] = mn.x; me[1] = mn.y; me[2] = mn.z; me[3] = mx.x; me[4] = mx.y; me[5] = mx.z;
+    __syncthreads();
+    const int h = 1 << k;
+    if (t + h < SUPER) {
+      const float* o = s_lvl[cur][t + h];
+      mn = min3(mn, v3(o[0], o[1], o[2])); mx = max3(mx, v3(o[3], o[4], o[5]));
+    }
+    cur ^= 1;                                          // the other buffer is written next level: no second barrier needed
+  }
+  if (t == 0) { super_box[2 * (size_t)s] = make_float4(mn.x, mn.y, mn.z, 0.0f); super_box[2 * (size_t)s + 1] = make_float4(mx.x, mx.y, mx.z, 0.0f); }
+}
+
+struct SpanCtx { const float4* nodes; const float4* mini_box; const float4* chunk_box; const float4* st; const float4* super_box; int first_leaf; };
+RT_DEV void fold(V3& mn, V3& mx, const float4 a, const float4 b) { mn = min3(mn, xyz(a)); mx = max3(mx, xyz(b)); }
+
+// What a 16-lane group fetches for ONE child [a, b] of a crossing node, five independent record loads per lane.
+// A child that does not cross a block boundary itself (a leaf, or a node k_refit_local finished) is one record: nodes[id].
+// Otherwise the range is folded from
+//   head: the <= 16 leaves of a's 16-leaf group from a on, the <= 3 whole 16-groups up to the end of a's 64-leaf chunk,
+//         the <= 3 whole chunks up to the end of a's block
+//   tail: the mirror image in front of b
+//   the whole blocks in between: <= 4 sparse-table entries (two overlapping ones per super-block touched) and, for the
+//         handful of ranges over more than two super-blocks, the whole super-blocks' boxes (16 per round)
+struct SpanLoads { float4 r[5][2]; uint32_t s1, s2; };
+RT_DEV void span_issue(const SpanCtx& c, uint32_t gl, bool local, int id, uint32_t a, uint32_t b, SpanLoads& L) {
+  const float4* leaf = c.nodes + 2 * (size_t)c.first_leaf;
+  const float4 e0 = make_float4(BOX_INF, BOX_INF, BOX_INF, 0.0f), e1 = make_float4(-BOX_INF, -BOX_INF, -BOX_INF, 0.0f);
+  bool ok[5];
+  const float4* p[5];
+  {   // head
+    const uint32_t k = (a & ~15u) + gl;
+    ok[0] = local ? (gl == 0u) : (k >= a);
+    p[0] = local ? (c.nodes + 2 * (size_t)id) : (leaf + 2 * (size_t)(k >= a ? k : a));
+    const bool mini = gl < 3u;
+    const uint32_t q = mini ? ((a >> 4) + 1u + gl) : ((a >> 6) + 1u + (gl - 3u));
+    ok[1] = !local && gl < 6u && (mini ? ((q >> 2) == (a >> 6)) : ((q >> 2) == (a >> 8)));
+    p[1] = (mini ? c.mini_box : c.chunk_box) + 2 * (size_t)(ok[1] ? q : 0u);
+  }
+  {   // tail
+    const uint32_t k = (b & ~15u) + gl;
+    ok[2] = !local && k <= b;
+    p[2] = leaf + 2 * (size_t)(ok[2] ? k : b);
+    const bool mini = gl < 3u;
+    const uint32_t q = mini ? (((b >> 6) << 2) + gl) : (((b >> 8) << 2) + (gl - 3u));
+    ok[3] = !local && gl < 6u && (mini ? (q < (b >> 4)) : (q < (b >> 6)));
+    p[3] = (mini ? c.mini_box : c.chunk_box) + 2 * (size_t)(ok[3] ? q : 0u);
+  }
+  {   // whole blocks m1 .. m2 in between: lanes 0-1 / 2-3 take one super-block's two entries each
+    const uint32_t b1 = a >> 8, b2 = b >> 8;
+    const bool any = !local && b2 > b1 + 1u;
+    const uint32_t m1 = b1 + 1u, m2 = any ? b2 - 1u : m1;
+    L.s1 = m1 >> 8; L.s2 = any ? (m2 >> 8) : L.s1;
+    const bool second = gl >= 2u;                       // lanes 2, 3: the last super-block touched (if it is another one)
+    const uint32_t sb = second ? L.s2 : L.s1;
+    const uint32_t xx = second ? 0u : (m1 & 255u);
+    const uint32_t yy = (second || L.s1 == L.s2) ? (m2 & 255u) : 255u;
+    ok[4] = any && gl < 4u && (!second || L.s1 != L.s2);
+    const uint32_t kk = 31u - (uint32_t)__clz((int)((ok[4] ? yy - xx : 0u) + 1u));
+    const uint32_t e = (gl & 1u) ? (yy + 1u - (1u << kk)) : xx;
+    p[4] = c.st + (ok[4] ? (((size_t)sb * ST_LEVELS + kk) * SUPER + e) * 2 : 0);
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) { L.r[k][0] = p[k][0]; L.r[k][1] = p[k][1]; }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) if (!ok[k]) { L.r[k][0] = e0; L.r[k][1] = e1; }
+}
+RT_DEV void span_fold(const SpanCtx& c, uint32_t gl, const SpanLoads& L, V3& omn, V3& omx) {
+  V3 mn = xyz(L.r[0][0]), mx = xyz(L.r[0][1]);
+#pragma unroll
+  for (int k = 1; k < 5; ++k) fold(mn, mx, L.r[k][0], L.r[k][1]);
+  for (uint32_t s = L.s1 + 1u + gl; s < L.s2; s += 16u) fold(mn, mx, c.super_box[2 * (size_t)s], c.super_box[2 * (size_t)s + 1]);   // whole super-blocks
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) {                   // the 16-lane group's reduction; the result is in each of its lanes
+    mn = min3(mn, v3(__shfl_xor(mn.x, o), __shfl_xor(mn.y, o), __shfl_xor(mn.z, o)));
+    mx = max3(mx, v3(__shfl_xor(mx.x, o), __shfl_xor(mx.y, o), __shfl_xor(mx.z, o)));
+  }
+  omn = mn; omx = mx;
+}
+
+// A wave looks at 64 consecutive internal nodes and finishes those whose range crosses a block boundary (3-4 % of all
+// nodes; up to ten in one wave), four at a time: 16 lanes per node, both children fetched in one round trip.
+__global__ __launch_bounds__(BLK) void k_refit_spans(const int32_t* __restrict__ span, const int32_t* __restrict__ child, uint32_t n_tri,
+                                                     float* nodes, float4* __restrict__ wide, const float4* __restrict__ mini_box,
+                                                     const float4* __restrict__ chunk_box, const float4* __restrict__ st,
+                                                     const float4* __restrict__ super_box, bool v2) {
+  __shared__ uint8_t s_list[BLK / 64][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t base = (blockIdx.x * (BLK / 64) + (uint32_t)w) * 64u, i = base + (uint32_t)lane;
+  int j = 0, c0 = 0, c1 = 0;
+  bool crossing = false;
+  if (i + 1 < n_tri) {
+    j = span[i];
+    crossing = ((min((int)i, j)) >> 8) != ((max((int)i, j)) >> 8);
+    if (crossing) { const int2 c = reinterpret_cast<const int2*>(child)[i]; c0 = c.x; c1 = c.y; }
+  }
+  const unsigned long long todo = __ballot(crossing);
+  if (!todo) return;
+  if (crossing) s_list[w][__popcll(todo & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))))] = (uint8_t)lane;   // the wave's own list: no barrier needed
+  __threadfence_block();
+  SpanCtx c; c.nodes = reinterpret_cast<const float4*>(nodes); c.mini_box = mini_box; c.chunk_box = chunk_box; c.st = st; c.super_box = super_box;
+  c.first_leaf = (int)n_tri - 1;
+  const int n_todo = __popcll(todo);
+  const uint32_t gl = (uint32_t)lane & 15u;
+  for (int r = 0; r < n_todo; r += 4) {
+    const int slot = r + (lane >> 4);
+    const bool act = slot < n_todo;
+    const int l = act ? (int)s_list[w][slot] : 0;
+    const int ii = (int)base + l, jj = __shfl(j, l), k0 = __shfl(c0, l), k1 = __shfl(c1, l);
+    if (!act) continue;
+    const uint32_t lo = (uint32_t)min(ii, jj), hi = (uint32_t)max(ii, jj);
+    // children: [lo, gamma] and [gamma + 1, hi], gamma = the sorted position child 0 ends at
+    const uint32_t gamma = (uint32_t)(k1 >= c.first_leaf ? k1 - c.first_leaf : k1) - 1u;
+    SpanLoads A, B;
+    span_issue(c, gl, (lo >> 8) == (gamma >> 8), k0, lo, gamma, A);
+    span_issue(c, gl, ((gamma + 1u) >> 8) == (hi >> 8), k1, gamma + 1u, hi, B);
+    V3 amn, amx, bmn, bmx;
+    span_fold(c, gl, A, amn, amx);
+    span_fold(c, gl, B, bmn, bmx);
+    if (gl == 0u) {
+      store_wide(wide, ii, k0, k1, c.first_leaf, amn, amx, bmn, bmx);
+      store_node(nodes, ii, min3(amn, bmn), enc_index(v2, (uint32_t)k0), max3(amx, bmx), enc_index(v2, (uint32_t)k1));
+    }
+  }
 }
 
 // ---------------------------------------------------------------- traversal layout
@@ -555,8 +783,32 @@ __global__ __launch_bounds__(BLK) void k_pack_tris(const float* __restrict__ tri
 
 }  // namespace
 
+#ifdef RT_SORT_TIMELINE
+extern "C" int rt_debug_sort_timeline(unsigned long long* out, size_t n_words) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sort_tl), sizeof(unsigned long long) * n_words);
+}
+#endif
+
 uint32_t rt_sort_tile_count(uint32_t n) { return (n + SORT_TILE - 1) / SORT_TILE; }
-size_t rt_sort_status_words(uint32_t n) { return (size_t)4 * rt_sort_tile_count(n) * RADIX; }
+// Tiles the chip certainly holds at once (occupancy query x CUs, with one block per CU of margin: the API can answer one
+// block per CU high, MI355X_MICROARCH.md "Residency"); grids up to this size need no start-order tickets.
+static uint32_t sort_resident_tiles() {
+  static int cached = -1;
+  if (cached < 0) {
+    int dev = 0, n_cu = 0, nb = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_onesweep<false>, BLK, 0) != hipSuccess || nb < 2) cached = 0;
+    else cached = (nb - 1) * n_cu;
+  }
+  return (uint32_t)cached;
+}
+// small sorts: all tiles run at once and latency matters (groups of 16 / 32: one or two round trips inside the group, one or
+// two over the groups); large ones: a tile's predecessors are long done, fewer words re-read
+static int sort_group_shift(uint32_t tiles) { return tiles <= 2048u ? 5 : 3; }
+static uint32_t sort_group_count(uint32_t tiles) { const int sh = sort_group_shift(tiles); return (tiles + (1u << sh) - 1u) >> sh; }
+// u32 words (used as 8-byte pairs): per pass the tiles' words, then the groups' words
+size_t rt_sort_status_words(uint32_t n) { const uint32_t t = rt_sort_tile_count(n); return (size_t)SORT_PASSES * ((size_t)t + sort_group_count(t)) * RADIX; }
+uint32_t rt_sort_hist_words() { return (uint32_t)(SORT_PASSES * RADIX); }
 
 uint32_t rt_bounds_words() { return 6u * 2048u; }   // grid_for's block cap x 6 partials
 void rt_launch_bounds(const RtBuildBuffers& b, hipStream_t s) {
@@ -566,41 +818,55 @@ void rt_launch_bounds(const RtBuildBuffers& b, hipStream_t s) {
 }
 
 void rt_launch_morton(const RtBuildBuffers& b, hipStream_t s) {
-  hipLaunchKernelGGL(k_morton, dim3(grid_for(b.n_tri, BLK)), dim3(BLK), 0, s, b.centroids, b.n_tri, b.bounds_f, b.codes,
-                     b.keys_a, b.vals_a, b.tile_status, rt_sort_status_words(b.n_tri));
+  // few, fat blocks: every block flushes its LDS digit histograms with one global atomic per non-empty bin
+  hipLaunchKernelGGL(k_morton, dim3(grid_for(b.n_tri, BLK * 16, 512)), dim3(BLK), 0, s, b.centroids, b.n_tri, b.bounds_f, b.codes,
+                     b.hist, b.tile_status, rt_sort_status_words(b.n_tri));
 }
 
 void rt_launch_sort(const RtBuildBuffers& b, hipStream_t s) {
   const uint32_t n = b.n_tri, tiles = rt_sort_tile_count(n);
-  // hist / tile_counter were zeroed by k_bounds_final, tile_status by k_morton
-  hipLaunchKernelGGL(k_sort_hist, dim3(grid_for(n, BLK * 8)), dim3(BLK), 0, s, b.keys_a, n, b.hist);
-  hipLaunchKernelGGL(k_sort_scan, dim3(4), dim3(BLK), 0, s, b.hist);
-  uint32_t *ki = b.keys_a, *vi = b.vals_a, *ko = b.keys_b, *vo = b.vals_b;
-  for (int p = 0; p < 4; ++p) {
-    hipLaunchKernelGGL(k_onesweep, dim3(tiles), dim3(BLK), 0, s, ki, vi, ko, vo, n, 8 * p, b.hist + p * RADIX,
-                       b.tile_status + (size_t)p * tiles * RADIX, b.tile_counter + p, b.err_flag);
-    uint32_t* t;
-    t = ki; ki = ko; ko = t;
-    t = vi; vi = vo; vo = t;
+  // hist / tile_counter were zeroed by k_bounds_final, tile_status by k_morton, which also filled hist
+  // codes -> a -> b -> a: the sorted keys / order end up in keys_a / vals_a
+  const uint32_t* ki = b.codes; const uint32_t* vi = nullptr;
+  uint32_t *ko = b.keys_a, *vo = b.vals_a;
+  for (int p = 0; p < SORT_PASSES; ++p) {
+    const size_t rows = (size_t)tiles + sort_group_count(tiles);
+    uint32_t* st = b.tile_status + (size_t)p * rows * RADIX;
+    const uint32_t st_bytes = (uint32_t)(rows * RADIX * sizeof(uint32_t));   // < 2^31: 65 536 tiles x 4 KB at 2^28 keys
+    const int gsh = sort_group_shift(tiles);
+    const int ticket = tiles > sort_resident_tiles() ? 1 : 0;
+    if (p == 0)
+      hipLaunchKernelGGL(k_onesweep<true>, dim3(tiles), dim3(BLK), 0, s, ki, vi, ko, vo, n, RADIX_BITS * p, b.hist + p * RADIX, st, tiles, st_bytes, gsh, ticket, b.tile_counter + p, b.err_flag);
+    else
+      hipLaunchKernelGGL(k_onesweep<false>, dim3(tiles), dim3(BLK), 0, s, ki, vi, ko, vo, n, RADIX_BITS * p, b.hist + p * RADIX, st, tiles, st_bytes, gsh, ticket, b.tile_counter + p, b.err_flag);
+    ki = ko; vi = vo;
+    ko = (ko == b.keys_a) ? b.keys_b : b.keys_a;
+    vo = (vo == b.vals_a) ? b.vals_b : b.vals_a;
   }
 }
 
 void rt_launch_karras(const RtBuildBuffers& b, hipStream_t s) {
   const uint32_t n_int = b.n_tri > 1 ? b.n_tri - 1 : 1;
-  hipLaunchKernelGGL(k_karras, dim3((n_int + BLK - 1) / BLK), dim3(BLK), 0, s, b.keys_a, b.n_tri, b.child, b.parent, b.visit);
+  hipLaunchKernelGGL(k_karras, dim3((n_int + BLK - 1) / BLK), dim3(BLK), 0, s, b.keys_a, b.n_tri, b.child, b.parent, b.span);
 }
 
-void rt_launch_refit(const RtBuildBuffers& b, float* nodes, float* tri_pos, float* tri_nor, float4* wide, float4* tri_pre,
-                     int leaf_shift, bool fenced, bool v2, hipStream_t s) {
-  const dim3 g((b.n_tri + BLK - 1) / BLK), blk(BLK);
-  if (fenced)
-    hipLaunchKernelGGL(k_refit<true>, g, blk, 0, s, b.pos, b.nor, b.vidx, b.nidx, b.vals_a, b.n_tri, b.child, b.parent, b.visit,
-                       nodes, tri_pos, tri_nor, wide, tri_pre, b.texcoords, b.tex_idx, b.material_ids, b.tri_uv, leaf_shift, v2);
-  else
-    hipLaunchKernelGGL(k_refit<false>, g, blk, 0, s, b.pos, b.nor, b.vidx, b.nidx, b.vals_a, b.n_tri, b.child, b.parent, b.visit,
-                       nodes, tri_pos, tri_nor, wide, tri_pre, b.texcoords, b.tex_idx, b.material_ids, b.tri_uv, leaf_shift, v2);
-  if (b.n_tri > 1)   // sets bit 8 of err_flag on any inconsistency
-    hipLaunchKernelGGL(k_refit_verify, dim3((b.n_tri - 1 + BLK - 1) / BLK), blk, 0, s, nodes, b.n_tri, b.child, b.visit, b.err_flag, v2);
+size_t rt_refit_table_float4s(uint32_t n_tri) {      // 16-leaf group boxes | 64-leaf chunk boxes | sparse tables of block boxes | super-block boxes
+  const size_t nb = ((size_t)n_tri + BLK - 1) / BLK, ns = (nb + SUPER - 1) / SUPER;
+  return 2 * nb * (BLK / 16) + 2 * nb * (BLK / 64) + 2 * ns * ST_LEVELS * SUPER + 2 * ns;
+}
+
+void rt_launch_refit(const RtBuildBuffers& b, float* nodes, float* tri_pos, float* tri_nor, float4* wide, float4* tri_pre, bool v2,
+                     hipStream_t s) {
+  const uint32_t nb = (b.n_tri + BLK - 1) / BLK, ns = (nb + SUPER - 1) / SUPER;
+  float4* mini_box = b.refit_tables;
+  float4* chunk_box = mini_box + 2 * (size_t)nb * (BLK / 16);
+  float4* st = chunk_box + 2 * (size_t)nb * (BLK / 64);
+  float4* super_box = st + 2 * (size_t)ns * ST_LEVELS * SUPER;
+  hipLaunchKernelGGL(k_refit_local, dim3(nb), dim3(BLK), 0, s, b.pos, b.nor, b.vidx, b.nidx, b.vals_a, b.n_tri, b.child, b.parent,
+                     nodes, tri_pos, tri_nor, wide, tri_pre, b.texcoords, b.tex_idx, b.material_ids, b.tri_uv, mini_box, chunk_box, v2);
+  if (b.n_tri <= BLK) return;                        // one block: every node is block-local
+  hipLaunchKernelGGL(k_refit_tables, dim3(ns), dim3(SUPER), 0, s, chunk_box, (b.n_tri + 63u) / 64u, nb, st, super_box);
+  hipLaunchKernelGGL(k_refit_spans, dim3((b.n_tri - 1 + BLK - 1) / BLK), dim3(BLK), 0, s, b.span, b.child, b.n_tri, nodes, wide, mini_box, chunk_box, st, super_box, v2);
 }
 
 // root_ref / err words live right behind the bounds words: see rt_api.hip (scratch[0], scratch[1])
