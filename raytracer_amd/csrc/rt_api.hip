@@ -93,7 +93,8 @@ struct rt_ctx {
   // build scratch
   DevBuf<uint32_t> bounds_enc, codes, keys_a, keys_b, vals_a, vals_b, hist, tile_status, tile_counter, words;
   DevBuf<float> bounds_f, centroids;
-  DevBuf<int32_t> child, parent, span;
+  DevBuf<int32_t> span, split;
+  DevBuf<uint32_t> cross_list;
   DevBuf<float4> refit_tables;
   bool built = false;      // codes / order valid
   uint32_t refit_fallbacks = 0;
@@ -268,7 +269,7 @@ extern "C" void rt_destroy(rt_ctx* ctx) {
   ctx->bounds_enc.release(); ctx->codes.release(); ctx->keys_a.release(); ctx->keys_b.release();
   ctx->vals_a.release(); ctx->vals_b.release(); ctx->hist.release(); ctx->tile_status.release();
   ctx->tile_counter.release(); ctx->words.release(); ctx->bounds_f.release(); ctx->centroids.release();
-  ctx->child.release(); ctx->parent.release(); ctx->span.release(); ctx->refit_tables.release();
+  ctx->span.release(); ctx->split.release(); ctx->cross_list.release(); ctx->refit_tables.release();
   ctx->own_nodes.release(); ctx->own_tri_pos.release(); ctx->own_tri_nor.release();
   ctx->wide.release(); ctx->tri_pre.release();
   ctx->texcoords.release(); ctx->tri_uv.release(); ctx->tidx.release(); ctx->matid.release(); ctx->materials.release();
@@ -350,9 +351,9 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
   HIPCHK(ctx->codes.ensure(T)); HIPCHK(ctx->keys_a.ensure(T)); HIPCHK(ctx->keys_b.ensure(T));
   HIPCHK(ctx->vals_a.ensure(T)); HIPCHK(ctx->vals_b.ensure(T));
   HIPCHK(ctx->hist.ensure(rt_sort_hist_words())); HIPCHK(ctx->tile_status.ensure(rt_sort_status_words(T)));
-  HIPCHK(ctx->tile_counter.ensure(4)); HIPCHK(ctx->words.ensure(4));
-  HIPCHK(ctx->child.ensure(2 * (size_t)(T > 1 ? T - 1 : 1))); HIPCHK(ctx->parent.ensure(N));
-  HIPCHK(ctx->span.ensure(T > 1 ? T - 1 : 1)); HIPCHK(ctx->refit_tables.ensure(rt_refit_table_float4s(T)));
+  HIPCHK(ctx->tile_counter.ensure(rt_build_counter_words())); HIPCHK(ctx->words.ensure(4));
+  HIPCHK(ctx->span.ensure(T > 1 ? T - 1 : 1)); HIPCHK(ctx->split.ensure(T > 1 ? T - 1 : 1));
+  HIPCHK(ctx->cross_list.ensure((size_t)64 * rt_cross_capacity(T))); HIPCHK(ctx->refit_tables.ensure(rt_refit_table_float4s(T)));
   HIPCHK(ctx->own_nodes.ensure((size_t)N * 8)); HIPCHK(ctx->own_tri_pos.ensure((size_t)T * 12));
   HIPCHK(ctx->own_tri_nor.ensure((size_t)T * 12));
   HIPCHK(ctx->wide.ensure((size_t)N * 4)); HIPCHK(ctx->tri_pre.ensure((size_t)T * 3));
@@ -362,7 +363,7 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
   b.bounds_enc = ctx->bounds_enc.p; b.bounds_f = ctx->bounds_f.p; b.centroids = ctx->centroids.p; b.codes = ctx->codes.p;
   b.keys_a = ctx->keys_a.p; b.keys_b = ctx->keys_b.p; b.vals_a = ctx->vals_a.p; b.vals_b = ctx->vals_b.p;
   b.hist = ctx->hist.p; b.tile_status = ctx->tile_status.p; b.tile_counter = ctx->tile_counter.p;
-  b.err_flag = ctx->words.p + 2; b.child = ctx->child.p; b.parent = ctx->parent.p; b.span = ctx->span.p; b.refit_tables = ctx->refit_tables.p;
+  b.err_flag = ctx->words.p + 2; b.span = ctx->span.p; b.split = ctx->split.p; b.cross_list = ctx->cross_list.p; b.refit_tables = ctx->refit_tables.p;
   b.n_sort_tiles = rt_sort_tile_count(T);
   b.texcoords = nullptr; b.tex_idx = nullptr; b.material_ids = nullptr; b.tri_uv = nullptr;
   if (ctx->surface_set) {          // surface records into BVH order by the refit, next to triPos / triNor
@@ -379,9 +380,9 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
   HIPCHK(hipEventRecord(ctx->ev[2], s));
   rt_launch_sort(b, s);
   HIPCHK(hipEventRecord(ctx->ev[3], s));
-  rt_launch_karras(b, s);
+  rt_launch_refit_local(b, ctx->own_nodes.p, ctx->own_tri_pos.p, ctx->own_tri_nor.p, ctx->wide.p, ctx->tri_pre.p, v2, s);
   HIPCHK(hipEventRecord(ctx->ev[4], s));
-  rt_launch_refit(b, ctx->own_nodes.p, ctx->own_tri_pos.p, ctx->own_tri_nor.p, ctx->wide.p, ctx->tri_pre.p, v2, s);
+  rt_launch_refit_upper(b, ctx->own_nodes.p, ctx->wide.p, v2, s);
   HIPCHK(hipEventRecord(ctx->ev[5], s));
   HIPCHK(hipGetLastError());
   // one read-back for the whole build: the sort's error word and the root record (the frame pipeline's screen-space
@@ -409,8 +410,8 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
     (void)hipEventElapsedTime(&out->ms_bounds, ctx->ev[0], ctx->ev[1]);
     (void)hipEventElapsedTime(&out->ms_morton, ctx->ev[1], ctx->ev[2]);
     (void)hipEventElapsedTime(&out->ms_sort, ctx->ev[2], ctx->ev[3]);
-    (void)hipEventElapsedTime(&out->ms_tree, ctx->ev[3], ctx->ev[4]);
-    (void)hipEventElapsedTime(&out->ms_refit, ctx->ev[4], ctx->ev[5]);
+    (void)hipEventElapsedTime(&out->ms_refit, ctx->ev[3], ctx->ev[4]);   // leaves + the tree and boxes inside every 256-leaf block
+    (void)hipEventElapsedTime(&out->ms_tree, ctx->ev[4], ctx->ev[5]);    // the nodes above the blocks
     (void)hipEventElapsedTime(&out->ms_pack, ctx->ev[6], ctx->ev[7]);
     out->ms_total = out->ms_bounds + out->ms_morton + out->ms_sort + out->ms_tree + out->ms_refit + out->ms_pack;
     out->n_tri = T; out->n_nodes = N;

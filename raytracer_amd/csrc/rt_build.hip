@@ -8,7 +8,7 @@
 //                  global digit histograms from k_morton, then per digit a single pass with
 //                  chained-scan decoupled look-back, wave64 ballot/popcount ranking (10 ballots per key) and an
 //                  LDS-staged scatter
-//   k_karras       Karras 2012 radix tree, one thread per internal node, ties broken by index
+//   (Karras 2012 radix tree, ties broken by index: inside k_refit_local / k_refit_upper, no kernel or arrays of its own)
 //   k_refit_*      one thread per leaf: emit BVH-ordered triangle buffers + leaf record, then climb the nodes inside
 //                  the thread's 256-leaf block through LDS; nodes above the blocks are range queries over leaf boxes
 //                  and sparse tables of block boxes (no hand-off between workgroups inside a launch)
@@ -93,6 +93,7 @@ __global__ __launch_bounds__(384) void k_bounds_final(const uint32_t* __restrict
   // the sort's global digit histograms and tile tickets start at zero (saves three memset launches)
   for (int i = threadIdx.x; i < SORT_PASSES * RADIX; i += 384) hist[i] = 0u;
   if (threadIdx.x < 4) tile_counter[threadIdx.x] = 0u;
+  for (int i = threadIdx.x; i < 64 * 32; i += 384) tile_counter[32 + i] = 0u;      // the refit's lists of block-crossing nodes (CROSS_SHARDS x CROSS_STRIDE)
   const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
   uint32_t v = (k < 3) ? 0xFFFFFFFFu : 0u;
   for (uint32_t b = lane; b < n_blocks; b += 64) {
@@ -410,13 +411,8 @@ RT_DEV int kdelta(const uint32_t* __restrict__ k, int n, int i, uint32_t ki, int
   return 32 + __clz((int)((uint32_t)i ^ (uint32_t)j));
 }
 
-__global__ __launch_bounds__(BLK) void k_karras(const uint32_t* __restrict__ k, uint32_t n_tri,
-                                                int32_t* __restrict__ child, int32_t* __restrict__ parent,
-                                                int32_t* __restrict__ span) {
-  const int n = (int)n_tri;
-  const int i = blockIdx.x * BLK + threadIdx.x;
-  if (i == 0) parent[0] = -1;
-  if (i >= n - 1) return;
+// Node i of the tree: the other end j of its leaf range and its split position gamma (children [lo, gamma], [gamma + 1, hi]).
+RT_DEV void karras_node(const uint32_t* __restrict__ k, int n, int i, int& j_out, int& gamma_out) {
   const uint32_t ki = k[i];
   const int d = (kdelta(k, n, i, ki, i + 1) - kdelta(k, n, i, ki, i - 1)) > 0 ? 1 : -1;
   const int dmin = kdelta(k, n, i, ki, i - d);
@@ -432,16 +428,79 @@ __global__ __launch_bounds__(BLK) void k_karras(const uint32_t* __restrict__ k, 
     if (kdelta(k, n, i, ki, i + (s + t) * d) > dnode) s += t;
     if (t == 1) break;
   }
-  const int gamma = i + s * d + min(d, 0);
+  j_out = j;
+  gamma_out = i + s * d + min(d, 0);
+}
+// node ids: internal k -> k, leaf k -> (T-1)+k
+RT_DEV void karras_children(int n, int i, int j, int gamma, int& c0, int& c1) {
   const int lo = min(i, j), hi = max(i, j);
-  // node ids: internal k -> k, leaf k -> (T-1)+k
-  const int c0 = (lo == gamma) ? (n - 1) + gamma : gamma;
-  const int c1 = (hi == gamma + 1) ? (n - 1) + gamma + 1 : gamma + 1;
-  child[2 * (size_t)i + 0] = c0; child[2 * (size_t)i + 1] = c1;
-  span[i] = j;                                     // the other end of the node's leaf range [min(i, j), max(i, j)] (one end is i itself)
-  // bit 30: this node's leaf range [lo, hi] lies inside one 256-leaf block of the refit (block-local climb)
-  const int link = i | (((lo >> 8) == (hi >> 8)) ? (1 << 30) : 0);
-  parent[c0] = link; parent[c1] = link;
+  c0 = (lo == gamma) ? (n - 1) + gamma : gamma;
+  c1 = (hi == gamma + 1) ? (n - 1) + gamma + 1 : gamma + 1;
+}
+
+// The same node from the same definition, for the nodes whose range crosses a 256-leaf block (k_refit_upper): their ranges
+// can be long, and galloping + bisection is a chain of ~3 log2(range) dependent key loads scattered over the key array.
+// delta(i, x) only shrinks as x moves away from i, so any probe sequence that brackets the last position with
+// delta > threshold gives Karras' answer: the search is done by 16 lanes at once (16 probes per round trip: the root's
+// ~80 dependent loads become ~14), and a probe 512 or more positions away is moved to the nearest multiple of 256, whose
+// key comes from the compact table of every block's first key (20 KB at 1.3 M triangles) instead of a cold line of the key array.
+struct KeyProbe {
+  const uint32_t* __restrict__ k; const uint32_t* __restrict__ tb; int n; int i; uint32_t ki;
+  RT_DEV int delta(int x) const {
+    if (x < 0 || x >= n) return -1;
+    const uint32_t kx = ((x & 255) == 0) ? tb[x >> 8] : k[x];
+    return (ki != kx) ? __clz((int)(ki ^ kx)) : 32 + __clz((int)((uint32_t)i ^ (uint32_t)x));
+  }
+  // offset s moved to the multiple of 256 (as a position) nearest to i + s d that lies strictly between lo and hi, if any
+  RT_DEV int snap(int d, int s, int lo, int hi) const {
+    const int xs = ((i + s * d) + 128) & ~255;
+    int ms = (xs - i) * d;
+    if (ms <= lo) ms += 256; else if (ms >= hi) ms -= 256;
+    return (ms > lo && ms < hi) ? ms : s;
+  }
+  // Largest s in [s_true, s_end) with delta(i + s d) > thr; delta(i + s_true d) > thr is given, s_end counts as failing.
+  // By a GROUP of 16 lanes (gl = lane in the group; every lane holds the same node): sixteen probes per round trip - first
+  // the doubling steps s_true + 2, 4, 8, ... (a short range ends in the first round, next to i), then 16-ary bisection.
+  // delta is monotone, so a round's answers are a run of passes followed by a run of failures.
+  RT_DEV int last_above(int lane, int d, int s_true, int s_end, int thr) const {
+    const int gl = lane & 15, g0 = lane & 48;
+    int lo = s_true, hi = s_end;
+    for (int round = 0; round < 2; ++round) {           // gallop: steps 2^1 .. 2^16, then 2^17 .. 2^32 (clipped by s_end)
+      const int sh = gl + 16 * round + 1;
+      long long sl = (long long)s_true + (sh < 40 ? (1ll << sh) : (1ll << 40));
+      const bool in = sl < (long long)hi;
+      int sv = in ? (int)sl : hi;
+      if (in && sh >= 9) sv = snap(d, sv, lo, hi);
+      const bool ok = in && delta(i + sv * d) > thr;
+      const uint32_t m = (uint32_t)__popc((uint32_t)((__ballot(ok) >> g0) & 0xFFFFull));     // passes are lanes 0 .. m-1
+      if (m > 0u) lo = __shfl(sv, g0 + (int)m - 1);
+      if (m < 16u) { hi = __shfl(sv, g0 + (int)m); break; }   // first failure (a lane beyond s_end holds hi itself)
+    }
+    while (hi - lo > 1) {                                // 15 interior probes per round
+      const int len = hi - lo;
+      int sv = lo + (int)(((long long)len * (gl + 1)) >> 4);
+      if (len >= 16 * 512 && gl < 15) sv = snap(d, sv, lo, hi);
+      const bool ok = gl < 15 && (sv == lo || delta(i + sv * d) > thr);
+      const uint32_t m = (uint32_t)__popc((uint32_t)((__ballot(ok) >> g0) & 0x7FFFull));
+      const int nlo = (m > 0u) ? __shfl(sv, g0 + (int)m - 1) : lo;
+      const int nhi = (m < 15u) ? __shfl(sv, g0 + (int)m) : hi;
+      lo = nlo; hi = nhi;
+    }
+    return lo;
+  }
+};
+// by a group of 16 lanes that all hold the same i
+RT_DEV void karras_node_wide(const uint32_t* __restrict__ k, const uint32_t* __restrict__ tb, int n, int i, int lane, int& j_out, int& gamma_out) {
+  KeyProbe P; P.k = k; P.tb = tb; P.n = n; P.i = i; P.ki = k[i];
+  const int d = (P.delta(i + 1) - P.delta(i - 1)) > 0 ? 1 : -1;
+  const int dmin = P.delta(i - d);
+  const int room = d > 0 ? (n - 1 - i) : i;             // positions on that side of i
+  const int l = P.last_above(lane, d, 1, room + 1, dmin);   // delta(i, i + d) > dmin by the choice of d
+  const int j = i + l * d;
+  const int dnode = P.delta(j);
+  const int sp = P.last_above(lane, d, 0, l, dnode);    // s = 0 is i itself
+  j_out = j;
+  gamma_out = i + sp * d + min(d, 0);
 }
 
 // ---------------------------------------------------------------- leaves + bottom-up refit
@@ -458,9 +517,9 @@ __global__ __launch_bounds__(BLK) void k_karras(const uint32_t* __restrict__ k, 
 // (Before: the ~1 % of nodes above the blocks were handed from CU to CU with write-through stores, an atomic counter and
 // sc1 loads per level - a ~70 us latency chain over the top ~12 levels with the chip nearly idle, 2.7x the traffic,
 // and a verify pass + fenced fallback to guard it.)
-constexpr int PARENT_LOCAL = 1 << 30;
-constexpr int PARENT_MASK = PARENT_LOCAL - 1;
-static_assert(BLK == 256, "k_karras marks block-local nodes with (lo >> 8) == (hi >> 8)");
+static_assert(BLK == 256, "block-local nodes: (lo >> 8) == (hi >> 8)");
+constexpr int CROSS_SHARDS = 64;           // lists of block-crossing nodes (one counter per 128-byte line, block b appends to list b % 64)
+constexpr int CROSS_STRIDE = 32;           // uint32 words between the shard counters
 constexpr int SUPER = 256;                 // blocks per super-block
 constexpr int ST_LEVELS = 9;               // 2^0 .. 2^8 blocks
 constexpr float BOX_INF = __builtin_inff();
@@ -486,31 +545,83 @@ RT_DEV void store_wide(float4* wide, int par, int c0, int c1, int first_leaf, V3
 
 __global__ __launch_bounds__(BLK) void k_refit_local(const float* __restrict__ pos, const float* __restrict__ nor,
                                                      const uint32_t* __restrict__ vidx, const uint32_t* __restrict__ nidx,
-                                                     const uint32_t* __restrict__ order, uint32_t n_tri,
-                                                     const int32_t* __restrict__ child, const int32_t* __restrict__ parent,
+                                                     const uint32_t* __restrict__ order, const uint32_t* __restrict__ keys, uint32_t n_tri,
+                                                     int32_t* __restrict__ span,
                                                      float* __restrict__ nodes, float* __restrict__ tri_pos,
                                                      float* __restrict__ tri_nor, float4* __restrict__ wide, float4* __restrict__ tri_pre,
                                                      const float* __restrict__ texcoords, const uint32_t* __restrict__ tex_idx,
                                                      const int32_t* __restrict__ material_ids, float4* __restrict__ tri_uv,
-                                                     float4* __restrict__ mini_box, float4* __restrict__ chunk_box, bool v2) {
+                                                     float4* __restrict__ mini_box, float4* __restrict__ chunk_box,
+                                                     uint32_t* __restrict__ block_key, uint32_t* cross_cnt, uint32_t* __restrict__ cross_list,
+                                                     uint32_t cross_cap, bool v2) {
   __shared__ float s_box[2 * BLK][6];      // [0, BLK): this block's leaves, [BLK, 2 BLK): internal nodes with index in the block's range
   __shared__ uint32_t s_visit[BLK];        // arrival counters of the block-local internal nodes
-  __shared__ int s_child[BLK][2];          // links of the internal nodes with index in the block's range, read once, coalesced:
-  __shared__ int s_parent[BLK];            // the climb then has no dependent global load per level
+  __shared__ int s_child[BLK][2];          // children of the block-local internal nodes
+  __shared__ int s_par[2 * BLK];           // parent of every leaf / internal slot if that parent is block-local, else -1
+  __shared__ uint32_t s_key[BLK + 2];      // sorted keys of positions S-1 .. S+256 (one halo key on either side)
+  __shared__ uint32_t s_cross[BLK / 64 + 1];   // crossing nodes per wave (exclusive offsets after the scan), [4] = the block's base in its shard list
+  const int n = (int)n_tri;
+  const int S = (int)(blockIdx.x * BLK), E = min(S + BLK - 1, n - 1);   // this block's leaves [S, E]
   s_visit[threadIdx.x] = 0u;
+  s_par[threadIdx.x] = -1; s_par[BLK + threadIdx.x] = -1;
+  for (int q = threadIdx.x; q < BLK + 2; q += BLK) { const int p = S - 1 + q; if (p >= 0 && p < n) s_key[q] = keys[p]; }
   const uint32_t j = blockIdx.x * BLK + threadIdx.x;
-  if (j + 1 < n_tri) {
-    const int2 c = reinterpret_cast<const int2*>(child)[j];
-    s_child[threadIdx.x][0] = c.x; s_child[threadIdx.x][1] = c.y;
-    s_parent[threadIdx.x] = parent[j];
-  }
-  __syncthreads();
-  const int first_leaf = (int)n_tri - 1;   // leaf j is node (T-1)+j, one triangle, start = j
-  V3 mn = v3(BOX_INF, BOX_INF, BOX_INF), mx = v3(-BOX_INF, -BOX_INF, -BOX_INF);
   const bool valid = j < n_tri;
-  int pe = -1;
+  const uint32_t ti = valid ? order[j] : 0u;           // issued here, used after the tree search below
+  __syncthreads();
+  if (threadIdx.x == 0) block_key[blockIdx.x] = s_key[1];   // key of position S: the coarse probes of k_refit_upper
+  // Karras 2012 on the keys in LDS, for internal node i = j.  A probe outside [S, E] is only ever compared with dmin, and a
+  // key farther away shares at most as long a prefix as the halo key of that side: if that halo key is still inside the
+  // node's range (delta > dmin) the range crosses the block boundary and the node is left to k_refit_upper; if not, every
+  // probe beyond it fails the comparison too.  Block-local nodes (~96 %) never leave LDS.
+  const int first_leaf = n - 1;            // leaf j is node (T-1)+j, one triangle, start = j
+  bool is_crossing = false;
+  if ((int)j < n - 1) {
+    const int i = (int)j;
+    const uint32_t ki = s_key[i - (S - 1)];
+    auto delta = [&](int x) -> int {                   // exact for x in [S-1, E+1]; -1 beyond (see above) and out of range
+      if (x < S - 1 || x > E + 1 || x < 0 || x >= n) return -1;
+      const uint32_t kx = s_key[x - (S - 1)];
+      return (ki != kx) ? __clz((int)(ki ^ kx)) : 32 + __clz((int)((uint32_t)i ^ (uint32_t)x));
+    };
+    const int d = (delta(i + 1) - delta(i - 1)) > 0 ? 1 : -1;
+    const int dmin = delta(i - d);
+    int other = -1;
+    if (!(delta(d > 0 ? E + 1 : S - 1) > dmin)) {      // the range ends inside the block
+      int lmax = 2;
+      while (delta(i + lmax * d) > dmin) lmax <<= 1;
+      int l = 0;
+      for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (delta(i + (l + t) * d) > dmin) l += t;
+      other = i + l * d;
+      const int dnode = delta(other);
+      int sp = 0;
+      for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
+        if (delta(i + (sp + t) * d) > dnode) sp += t;
+        if (t == 1) break;
+      }
+      const int gamma = i + sp * d + min(d, 0);
+      int c0, c1;
+      karras_children(n, i, other, gamma, c0, c1);
+      s_child[threadIdx.x][0] = c0; s_child[threadIdx.x][1] = c1;
+      s_par[(c0 >= first_leaf) ? (c0 - first_leaf - S) : (BLK + c0 - S)] = i;
+      s_par[(c1 >= first_leaf) ? (c1 - first_leaf - S) : (BLK + c1 - S)] = i;
+    }
+    span[i] = other;                                   // -1: crosses a block boundary
+    is_crossing = other < 0;
+  }
+  // the crossing nodes of the chip as 64 compact lists (k_refit_search / k_refit_spans then spend their lanes on those 3-4 %
+  // of the nodes only): one atomic per block reserves the block's run in list (block % 64)
+  const unsigned long long cross_mask = __ballot(is_crossing);
+  if ((threadIdx.x & 63) == 0) s_cross[threadIdx.x >> 6] = (uint32_t)__popcll(cross_mask);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int w = 0; w < BLK / 64; ++w) { const uint32_t c = s_cross[w]; s_cross[w] = run; run += c; }
+    s_cross[BLK / 64] = run ? atomicAdd(cross_cnt + (blockIdx.x % CROSS_SHARDS) * CROSS_STRIDE, run) : 0u;
+  }
+  V3 mn = v3(BOX_INF, BOX_INF, BOX_INF), mx = v3(-BOX_INF, -BOX_INF, -BOX_INF);
   if (valid) {
-    const uint32_t ti = order[j];
     V3 p[3];
     float4* tp = reinterpret_cast<float4*>(tri_pos) + (size_t)j * 3;
     float4* tn = reinterpret_cast<float4*>(tri_nor) + (size_t)j * 3;
@@ -538,7 +649,6 @@ __global__ __launch_bounds__(BLK) void k_refit_local(const float* __restrict__ p
     // true triangle bounds (web/script.js:309-316)
     mn = v3(fminf(fminf(p[0].x, p[1].x), p[2].x), fminf(fminf(p[0].y, p[1].y), p[2].y), fminf(fminf(p[0].z, p[1].z), p[2].z));
     mx = v3(fmaxf(fmaxf(p[0].x, p[1].x), p[2].x), fmaxf(fmaxf(p[0].y, p[1].y), p[2].y), fmaxf(fmaxf(p[0].z, p[1].z), p[2].z));
-    pe = parent[first_leaf + (int)j];                  // link to the parent of the leaf
     store_node(nodes, first_leaf + (int)j, mn, enc_index(v2, j), mx, enc_leaf_b(v2, 1u));   // A = tri_start, B = -count (script.js:348,554,558)
   }
   {   // boxes of aligned groups of 16 and 64 leaves (the valid ones), from one xor butterfly: the ragged ends of the ranges in k_refit_spans
@@ -565,8 +675,9 @@ __global__ __launch_bounds__(BLK) void k_refit_local(const float* __restrict__ p
     float* sb = s_box[cur_slot];
     sb[0] = mn.x; sb[1] = mn.y; sb[2] = mn.z; sb[3] = mx.x; sb[4] = mx.y; sb[5] = mx.z;
   }
-  while (pe >= 0 && (pe & PARENT_LOCAL)) {             // a parent whose range leaves the block: k_refit_spans
-    const int par = pe & PARENT_MASK;
+  int pe = s_par[threadIdx.x];
+  while (pe >= 0) {                                    // -1: the parent's range leaves the block (k_refit_upper), or this is the root
+    const int par = pe;
     __threadfence_block();                             // the box is in LDS before the counter moves (one LDS, in-order)
     const uint32_t arrived = atomicAdd(&s_visit[par & (BLK - 1)], 1u);
     if (arrived == 0) break;                           // the sibling's thread will finish this node
@@ -576,7 +687,7 @@ __global__ __launch_bounds__(BLK) void k_refit_local(const float* __restrict__ p
     const int sslot = (sib >= first_leaf) ? ((sib - first_leaf) & (BLK - 1)) : (BLK + (sib & (BLK - 1)));
     const float* ss = s_box[sslot];
     mn = min3(mn, v3(ss[0], ss[1], ss[2])); mx = max3(mx, v3(ss[3], ss[4], ss[5]));
-    pe = s_parent[par & (BLK - 1)];
+    pe = s_par[BLK + (par & (BLK - 1))];
     cur = par;
     cur_slot = BLK + (par & (BLK - 1));
     float* sb = s_box[cur_slot];
@@ -591,14 +702,37 @@ __global__ __launch_bounds__(BLK) void k_refit_local(const float* __restrict__ p
     store_wide(wide, (int)j, c0, c1, first_leaf, v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]), v3(b[0], b[1], b[2]), v3(b[3], b[4], b[5]));
     store_node(nodes, (int)j, v3(m[0], m[1], m[2]), enc_index(v2, (uint32_t)c0), v3(m[3], m[4], m[5]), enc_index(v2, (uint32_t)c1));   // v1: indices as f32 values (F11)
   }
+  if (is_crossing) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t at = s_cross[BLK / 64] + s_cross[threadIdx.x >> 6] + (uint32_t)__popcll(cross_mask & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+    cross_list[(size_t)(blockIdx.x % CROSS_SHARDS) * cross_cap + at] = j;
+  }
 }
 
-// Sparse table over the boxes of one super-block's 256 blocks: st[(s * 9 + k) * 256 + x] = box of blocks [x, x + 2^k) of
-// super-block s (entries reaching past block 255 are never queried); missing blocks count as empty boxes.
-__global__ __launch_bounds__(SUPER) void k_refit_tables(const float4* __restrict__ chunk_box, uint32_t n_chunks, uint32_t n_blocks,
-                                                        float4* __restrict__ st, float4* __restrict__ super_box) {
+// Two independent jobs in one launch (neither is large enough to fill the chip):
+//  blocks [0, n_super): sparse table over the boxes of one super-block's 256 blocks: st[(s * 9 + k) * 256 + x] = box of blocks
+//    [x, x + 2^k) of super-block s (entries reaching past block 255 are never queried); missing blocks count as empty boxes;
+//  the other blocks: the tree search of the block-crossing nodes from their compact lists, 16 lanes per node (they are 3-4 %
+//    of the nodes: searched inside a kernel with one lane per node, every wave waited for its two or three long searches
+//    with 60 idle lanes, five rounds of blocks deep): wave -> shard list (wave % 64), four entries per step.
+__global__ __launch_bounds__(SUPER) void k_refit_mid(const float4* __restrict__ chunk_box, uint32_t n_chunks, uint32_t n_blocks, uint32_t n_super,
+                                                     float4* __restrict__ st, float4* __restrict__ super_box,
+                                                     const uint32_t* __restrict__ keys, const uint32_t* __restrict__ block_key, uint32_t n_tri,
+                                                     const uint32_t* __restrict__ cross_cnt, const uint32_t* __restrict__ cross_list, uint32_t cross_cap,
+                                                     int32_t* __restrict__ span, int32_t* __restrict__ split) {
   __shared__ float s_lvl[2][SUPER][6];
   const int t = threadIdx.x;
+  if (blockIdx.x >= n_super) {
+    const uint32_t gw = (blockIdx.x - n_super) * (SUPER / 64) + (uint32_t)(t >> 6), n_waves = (gridDim.x - n_super) * (SUPER / 64);
+    const uint32_t shard = gw % CROSS_SHARDS, cnt = cross_cnt[shard * CROSS_STRIDE];
+    for (uint32_t q = (gw / CROSS_SHARDS) * 4u + (uint32_t)((t & 63) >> 4); q < cnt; q += (n_waves / CROSS_SHARDS) * 4u) {   // 16 lanes per node
+      const int i = (int)cross_list[(size_t)shard * cross_cap + q];
+      int j, gamma;
+      karras_node_wide(keys, block_key, (int)n_tri, i, t & 63, j, gamma);
+      if ((t & 15) == 0) { span[i] = j; split[i] = gamma; }
+    }
+    return;
+  }
   const uint32_t s = blockIdx.x, b = s * SUPER + (uint32_t)t;
   V3 mn = v3(BOX_INF, BOX_INF, BOX_INF), mx = v3(-BOX_INF, -BOX_INF, -BOX_INF);
   if (b < n_blocks)
@@ -688,39 +822,25 @@ RT_DEV void span_fold(const SpanCtx& c, uint32_t gl, const SpanLoads& L, V3& omn
   omn = mn; omx = mx;
 }
 
-// A wave looks at 64 consecutive internal nodes and finishes those whose range crosses a block boundary (3-4 % of all
-// nodes; up to ten in one wave), four at a time: 16 lanes per node, both children fetched in one round trip.
-__global__ __launch_bounds__(BLK) void k_refit_spans(const int32_t* __restrict__ span, const int32_t* __restrict__ child, uint32_t n_tri,
+// The boxes and records of the block-crossing nodes, from the shard lists: 16 lanes per node (four nodes per wave and
+// step), both children fetched in one round trip.  span / split: the node's range end and split position (k_refit_mid).
+__global__ __launch_bounds__(BLK) void k_refit_spans(const uint32_t* __restrict__ cross_cnt, const uint32_t* __restrict__ cross_list, uint32_t cross_cap,
+                                                     const int32_t* __restrict__ span, const int32_t* __restrict__ split, uint32_t n_tri,
                                                      float* nodes, float4* __restrict__ wide, const float4* __restrict__ mini_box,
                                                      const float4* __restrict__ chunk_box, const float4* __restrict__ st,
                                                      const float4* __restrict__ super_box, bool v2) {
-  __shared__ uint8_t s_list[BLK / 64][64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const uint32_t base = (blockIdx.x * (BLK / 64) + (uint32_t)w) * 64u, i = base + (uint32_t)lane;
-  int j = 0, c0 = 0, c1 = 0;
-  bool crossing = false;
-  if (i + 1 < n_tri) {
-    j = span[i];
-    crossing = ((min((int)i, j)) >> 8) != ((max((int)i, j)) >> 8);
-    if (crossing) { const int2 c = reinterpret_cast<const int2*>(child)[i]; c0 = c.x; c1 = c.y; }
-  }
-  const unsigned long long todo = __ballot(crossing);
-  if (!todo) return;
-  if (crossing) s_list[w][__popcll(todo & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))))] = (uint8_t)lane;   // the wave's own list: no barrier needed
-  __threadfence_block();
+  const int lane = threadIdx.x & 63;
+  const uint32_t gw = blockIdx.x * (BLK / 64) + (threadIdx.x >> 6), n_waves = gridDim.x * (BLK / 64);
+  const uint32_t shard = gw % CROSS_SHARDS, cnt = cross_cnt[shard * CROSS_STRIDE];
   SpanCtx c; c.nodes = reinterpret_cast<const float4*>(nodes); c.mini_box = mini_box; c.chunk_box = chunk_box; c.st = st; c.super_box = super_box;
   c.first_leaf = (int)n_tri - 1;
-  const int n_todo = __popcll(todo);
   const uint32_t gl = (uint32_t)lane & 15u;
-  for (int r = 0; r < n_todo; r += 4) {
-    const int slot = r + (lane >> 4);
-    const bool act = slot < n_todo;
-    const int l = act ? (int)s_list[w][slot] : 0;
-    const int ii = (int)base + l, jj = __shfl(j, l), k0 = __shfl(c0, l), k1 = __shfl(c1, l);
-    if (!act) continue;
-    const uint32_t lo = (uint32_t)min(ii, jj), hi = (uint32_t)max(ii, jj);
-    // children: [lo, gamma] and [gamma + 1, hi], gamma = the sorted position child 0 ends at
-    const uint32_t gamma = (uint32_t)(k1 >= c.first_leaf ? k1 - c.first_leaf : k1) - 1u;
+  for (uint32_t q = (gw / CROSS_SHARDS) * 4u + (uint32_t)(lane >> 4); q < cnt; q += (n_waves / CROSS_SHARDS) * 4u) {
+    const int ii = (int)cross_list[(size_t)shard * cross_cap + q];
+    const int jj = span[ii], gm = split[ii];
+    int k0, k1;
+    karras_children((int)n_tri, ii, jj, gm, k0, k1);
+    const uint32_t lo = (uint32_t)min(ii, jj), hi = (uint32_t)max(ii, jj), gamma = (uint32_t)gm;   // children: [lo, gamma] and [gamma + 1, hi]
     SpanLoads A, B;
     span_issue(c, gl, (lo >> 8) == (gamma >> 8), k0, lo, gamma, A);
     span_issue(c, gl, ((gamma + 1u) >> 8) == (hi >> 8), k1, gamma + 1u, hi, B);
@@ -845,28 +965,51 @@ void rt_launch_sort(const RtBuildBuffers& b, hipStream_t s) {
   }
 }
 
-void rt_launch_karras(const RtBuildBuffers& b, hipStream_t s) {
-  const uint32_t n_int = b.n_tri > 1 ? b.n_tri - 1 : 1;
-  hipLaunchKernelGGL(k_karras, dim3((n_int + BLK - 1) / BLK), dim3(BLK), 0, s, b.keys_a, b.n_tri, b.child, b.parent, b.span);
-}
+// capacity of one of the 64 lists of block-crossing nodes: every node of every block that appends to it
+uint32_t rt_cross_capacity(uint32_t n_tri) { const uint32_t nb = (n_tri + BLK - 1) / BLK; return ((nb + CROSS_SHARDS - 1) / CROSS_SHARDS) * BLK; }
+uint32_t rt_build_counter_words() { return 32u + CROSS_SHARDS * CROSS_STRIDE; }   // sort tickets | shard counters of the crossing-node lists
 
-size_t rt_refit_table_float4s(uint32_t n_tri) {      // 16-leaf group boxes | 64-leaf chunk boxes | sparse tables of block boxes | super-block boxes
+// 16-leaf group boxes | 64-leaf chunk boxes | sparse tables of block boxes | super-block boxes | every block's first key
+size_t rt_refit_table_float4s(uint32_t n_tri) {
   const size_t nb = ((size_t)n_tri + BLK - 1) / BLK, ns = (nb + SUPER - 1) / SUPER;
-  return 2 * nb * (BLK / 16) + 2 * nb * (BLK / 64) + 2 * ns * ST_LEVELS * SUPER + 2 * ns;
+  return 2 * nb * (BLK / 16) + 2 * nb * (BLK / 64) + 2 * ns * ST_LEVELS * SUPER + 2 * ns + (nb + 3) / 4;
 }
 
-void rt_launch_refit(const RtBuildBuffers& b, float* nodes, float* tri_pos, float* tri_nor, float4* wide, float4* tri_pre, bool v2,
-                     hipStream_t s) {
-  const uint32_t nb = (b.n_tri + BLK - 1) / BLK, ns = (nb + SUPER - 1) / SUPER;
-  float4* mini_box = b.refit_tables;
-  float4* chunk_box = mini_box + 2 * (size_t)nb * (BLK / 16);
-  float4* st = chunk_box + 2 * (size_t)nb * (BLK / 64);
-  float4* super_box = st + 2 * (size_t)ns * ST_LEVELS * SUPER;
-  hipLaunchKernelGGL(k_refit_local, dim3(nb), dim3(BLK), 0, s, b.pos, b.nor, b.vidx, b.nidx, b.vals_a, b.n_tri, b.child, b.parent,
-                     nodes, tri_pos, tri_nor, wide, tri_pre, b.texcoords, b.tex_idx, b.material_ids, b.tri_uv, mini_box, chunk_box, v2);
+namespace {
+struct RefitTables { float4 *mini_box, *chunk_box, *st, *super_box; uint32_t* block_key; uint32_t nb, ns; };
+RefitTables refit_tables(const RtBuildBuffers& b) {
+  RefitTables t;
+  t.nb = (b.n_tri + BLK - 1) / BLK; t.ns = (t.nb + SUPER - 1) / SUPER;
+  t.mini_box = b.refit_tables;
+  t.chunk_box = t.mini_box + 2 * (size_t)t.nb * (BLK / 16);
+  t.st = t.chunk_box + 2 * (size_t)t.nb * (BLK / 64);
+  t.super_box = t.st + 2 * (size_t)t.ns * ST_LEVELS * SUPER;
+  t.block_key = reinterpret_cast<uint32_t*>(t.super_box + 2 * (size_t)t.ns);
+  return t;
+}
+}  // namespace
+
+// leaves, triangle records, the tree and boxes inside every 256-leaf block (keys_a / vals_a = the sorted keys / order)
+void rt_launch_refit_local(const RtBuildBuffers& b, float* nodes, float* tri_pos, float* tri_nor, float4* wide, float4* tri_pre, bool v2,
+                           hipStream_t s) {
+  const RefitTables t = refit_tables(b);
+  hipLaunchKernelGGL(k_refit_local, dim3(t.nb), dim3(BLK), 0, s, b.pos, b.nor, b.vidx, b.nidx, b.vals_a, b.keys_a, b.n_tri, b.span,
+                     nodes, tri_pos, tri_nor, wide, tri_pre, b.texcoords, b.tex_idx, b.material_ids, b.tri_uv, t.mini_box, t.chunk_box,
+                     t.block_key, b.tile_counter + 32, b.cross_list, rt_cross_capacity(b.n_tri), v2);
+}
+
+// the nodes above the blocks: sparse tables of block boxes, then tree search + range queries for every crossing node
+void rt_launch_refit_upper(const RtBuildBuffers& b, float* nodes, float4* wide, bool v2, hipStream_t s) {
   if (b.n_tri <= BLK) return;                        // one block: every node is block-local
-  hipLaunchKernelGGL(k_refit_tables, dim3(ns), dim3(SUPER), 0, s, chunk_box, (b.n_tri + 63u) / 64u, nb, st, super_box);
-  hipLaunchKernelGGL(k_refit_spans, dim3((b.n_tri - 1 + BLK - 1) / BLK), dim3(BLK), 0, s, b.span, b.child, b.n_tri, nodes, wide, mini_box, chunk_box, st, super_box, v2);
+  const RefitTables t = refit_tables(b);
+  const uint32_t* cnt = b.tile_counter + 32;
+  const uint32_t cap = rt_cross_capacity(b.n_tri);
+  // sparse tables of block boxes || tree search of the crossing nodes; then their boxes (both list-driven: fixed grids)
+  const uint32_t search_blocks = 2048;
+  hipLaunchKernelGGL(k_refit_mid, dim3(t.ns + search_blocks), dim3(SUPER), 0, s, t.chunk_box, (b.n_tri + 63u) / 64u, t.nb, t.ns, t.st, t.super_box,
+                     b.keys_a, t.block_key, b.n_tri, cnt, b.cross_list, cap, b.span, b.split);
+  hipLaunchKernelGGL(k_refit_spans, dim3(2048), dim3(BLK), 0, s, cnt, b.cross_list, cap, b.span, b.split, b.n_tri, nodes, wide,
+                     t.mini_box, t.chunk_box, t.st, t.super_box, v2);
 }
 
 // root_ref / err words live right behind the bounds words: see rt_api.hip (scratch[0], scratch[1])

@@ -106,11 +106,11 @@ struct RtBuildBuffers {
   uint32_t* vals_a; uint32_t* vals_b;
   uint32_t* hist;           // [rt_sort_hist_words()] global digit histograms (raw counts; scanned inside the sort passes)
   uint32_t* tile_status;    // [passes][n_tiles][digits] look-back words
-  uint32_t* tile_counter;   // [4]
+  uint32_t* tile_counter;   // [rt_build_counter_words()] sort tickets, then the shard counters of cross_list
   uint32_t* err_flag;       // [1]
-  int32_t*  child;          // [2*(T-1)] child node ids
-  int32_t*  parent;         // [2T-1] parent links; bit 30 = the parent's leaf range lies inside one 256-leaf block
   int32_t*  span;           // [T-1] the other end j of node i's leaf range [min(i,j), max(i,j)]
+  int32_t*  split;          // [T-1] split position of the nodes whose range crosses a 256-leaf block (the others never leave LDS)
+  uint32_t* cross_list;     // [64 * rt_cross_capacity(T)] those nodes, as 64 compact lists
   float4*   refit_tables;   // [rt_refit_table_float4s(T)] block boxes, per-super-block sparse tables, super-block boxes
   uint32_t  n_sort_tiles;
   // optional surface inputs (NULL texcoords = none): the refit also writes the BVH-order records tri_uv [2T float4]
@@ -123,11 +123,13 @@ uint32_t rt_sort_hist_words();
 void rt_launch_bounds(const RtBuildBuffers& b, hipStream_t s);
 void rt_launch_morton(const RtBuildBuffers& b, hipStream_t s);
 void rt_launch_sort(const RtBuildBuffers& b, hipStream_t s);      // result in keys_a / vals_a
-void rt_launch_karras(const RtBuildBuffers& b, hipStream_t s);
 // also writes the traversal layout (wide, tri_pre) from the values it already holds: builds need no pack pass
-void rt_launch_refit(const RtBuildBuffers& b, float* nodes, float* tri_pos, float* tri_nor, float4* wide, float4* tri_pre,
-                     bool v2, hipStream_t s);
+void rt_launch_refit_local(const RtBuildBuffers& b, float* nodes, float* tri_pos, float* tri_nor, float4* wide, float4* tri_pre,
+                           bool v2, hipStream_t s);
+void rt_launch_refit_upper(const RtBuildBuffers& b, float* nodes, float4* wide, bool v2, hipStream_t s);
 size_t rt_refit_table_float4s(uint32_t n_tri);
+uint32_t rt_cross_capacity(uint32_t n_tri);
+uint32_t rt_build_counter_words();
 // derive the traversal layout from the interchange buffers; writes the root ref / error bits
 void rt_launch_pack_impl(const RtBvhDev& bvh, uint32_t* d_root_ref, uint32_t* d_err, hipStream_t s);
 
