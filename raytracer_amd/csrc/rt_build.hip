@@ -53,13 +53,33 @@ RT_DEV uint32_t wave_max_u32(uint32_t v) {
   return v;
 }
 
+// ---------------------------------------------------------------- mesh layout in HBM
+// The loadObj arrays arrive as separate index arrays (vertex, normal, texcoord triples, material ids).  The refit fetches a
+// triangle's indices through the sort order, and three or four 12-byte gathers from separate arrays pull three or four
+// 128-byte lines per triangle where ONE record per triangle pulls 1.3: at upload (rt_set_mesh / rt_set_surface) the index
+// arrays are interleaved into {v0 v1 v2 n0 | n1 n2 t0 t1 | t2 material - -}: 32 bytes per triangle, 48 with a surface.
+__global__ __launch_bounds__(BLK) void k_interleave(const uint32_t* __restrict__ vidx, const uint32_t* __restrict__ nidx,
+                                                    const uint32_t* __restrict__ tex_idx, const int32_t* __restrict__ material_ids,
+                                                    uint32_t n_tri, uint4* __restrict__ tri_rec) {
+  const uint32_t t = blockIdx.x * BLK + threadIdx.x;
+  if (t >= n_tri) return;
+  const uint32_t i0 = vidx[3 * (size_t)t + 0], i1 = vidx[3 * (size_t)t + 1], i2 = vidx[3 * (size_t)t + 2];
+  const uint32_t n0 = nidx[3 * (size_t)t + 0], n1 = nidx[3 * (size_t)t + 1], n2 = nidx[3 * (size_t)t + 2];
+  uint4* rec = tri_rec + (size_t)t * (tex_idx ? 3 : 2);
+  if (tex_idx) {
+    const uint32_t t0 = tex_idx[3 * (size_t)t + 0], t1 = tex_idx[3 * (size_t)t + 1], t2 = tex_idx[3 * (size_t)t + 2];
+    rec[0] = make_uint4(i0, i1, i2, n0); rec[1] = make_uint4(n1, n2, t0, t1);
+    rec[2] = make_uint4(t2, material_ids ? (uint32_t)material_ids[t] : 0xFFFFFFFFu, 0u, 0u);
+  } else { rec[0] = make_uint4(i0, i1, i2, n0); rec[1] = make_uint4(n1, n2, 0u, 0u); }
+}
+
 // ---------------------------------------------------------------- centroid bounds
 // Two stages, no atomics: every block leaves its six ordered-uint partials in its own slot (2048 blocks x 6 same-address
 // atomicMin/Max serialised at ~26 ns each: 53 of the kernel's 62 us at 1.3 M triangles), one block folds the slots.
 // Also keeps every centroid (12 B/triangle, coalesced) so that k_morton streams them instead of repeating the
 // three-vertex gather through the index buffer (48 B/triangle of scattered reads).
 __global__ __launch_bounds__(BLK) void k_bounds(const float* __restrict__ pos, const uint32_t* __restrict__ vidx,
-                                                uint32_t n_tri, uint32_t* __restrict__ part /* [gridDim.x][6] */,
+                                                uint32_t n_tri, uint32_t* __restrict__ part /* [6][gridDim.x] */,
                                                 float* __restrict__ centroids /* [3T] */) {
   uint32_t mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u};
   for (uint32_t t = blockIdx.x * BLK + threadIdx.x; t < n_tri; t += gridDim.x * BLK) {
@@ -81,7 +101,7 @@ __global__ __launch_bounds__(BLK) void k_bounds(const float* __restrict__ pos, c
     const int k = threadIdx.x;
     uint32_t v = s[k][0];
     for (int w = 1; w < BLK / 64; ++w) v = (k < 3) ? min(v, s[k][w]) : max(v, s[k][w]);
-    part[(size_t)blockIdx.x * 6 + k] = v;
+    part[(size_t)k * gridDim.x + blockIdx.x] = v;        // component-major: k_bounds_final reads them coalesced
   }
 }
 
@@ -96,9 +116,12 @@ __global__ __launch_bounds__(384) void k_bounds_final(const uint32_t* __restrict
   for (int i = threadIdx.x; i < 64 * 32; i += 384) tile_counter[32 + i] = 0u;      // the refit's lists of block-crossing nodes (CROSS_SHARDS x CROSS_STRIDE)
   const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
   uint32_t v = (k < 3) ? 0xFFFFFFFFu : 0u;
-  for (uint32_t b = lane; b < n_blocks; b += 64) {
-    const uint32_t x = part[(size_t)b * 6 + k];
-    v = (k < 3) ? min(v, x) : max(v, x);
+  {   // wave k folds component k: all loads of a wave issued before the first is used (<= 2048 partials: 32 per lane)
+    uint32_t x[32];
+#pragma unroll
+    for (int it = 0; it < 32; ++it) { const uint32_t b = (uint32_t)lane + 64u * it; x[it] = (b < n_blocks) ? part[(size_t)k * n_blocks + b] : v; }
+#pragma unroll
+    for (int it = 0; it < 32; ++it) v = (k < 3) ? min(v, x[it]) : max(v, x[it]);
   }
   v = (k < 3) ? wave_min_u32(v) : wave_max_u32(v);
   if (lane == 0) s[k] = v;
@@ -544,13 +567,12 @@ RT_DEV void store_wide(float4* wide, int par, int c0, int c1, int first_leaf, V3
 }
 
 __global__ __launch_bounds__(BLK) void k_refit_local(const float* __restrict__ pos, const float* __restrict__ nor,
-                                                     const uint32_t* __restrict__ vidx, const uint32_t* __restrict__ nidx,
+                                                     const uint4* __restrict__ tri_rec,
                                                      const uint32_t* __restrict__ order, const uint32_t* __restrict__ keys, uint32_t n_tri,
                                                      int32_t* __restrict__ span,
                                                      float* __restrict__ nodes, float* __restrict__ tri_pos,
                                                      float* __restrict__ tri_nor, float4* __restrict__ wide, float4* __restrict__ tri_pre,
-                                                     const float* __restrict__ texcoords, const uint32_t* __restrict__ tex_idx,
-                                                     const int32_t* __restrict__ material_ids, float4* __restrict__ tri_uv,
+                                                     const float* __restrict__ texcoords, float4* __restrict__ tri_uv,
                                                      float4* __restrict__ mini_box, float4* __restrict__ chunk_box,
                                                      uint32_t* __restrict__ block_key, uint32_t* cross_cnt, uint32_t* __restrict__ cross_list,
                                                      uint32_t cross_cap, bool v2) {
@@ -625,10 +647,13 @@ __global__ __launch_bounds__(BLK) void k_refit_local(const float* __restrict__ p
     V3 p[3];
     float4* tp = reinterpret_cast<float4*>(tri_pos) + (size_t)j * 3;
     float4* tn = reinterpret_cast<float4*>(tri_nor) + (size_t)j * 3;
+    const uint4* rec = tri_rec + (size_t)ti * (texcoords ? 3 : 2);     // k_bounds: {v0 v1 v2 n0 | n1 n2 t0 t1 | t2 material - -}
+    const uint4 ra = rec[0], rb = rec[1];
+    const uint32_t vi[3] = {ra.x, ra.y, ra.z}, ni[3] = {ra.w, rb.x, rb.y};
 #pragma unroll
     for (int v = 0; v < 3; ++v) {                     // web/script.js:530-545
-      p[v] = load_vtx(pos, vidx[3 * (size_t)ti + v]);
-      V3 nn = load_vtx(nor, nidx[3 * (size_t)ti + v]);
+      p[v] = load_vtx(pos, vi[v]);
+      V3 nn = load_vtx(nor, ni[v]);
       tp[v] = make_float4(p[v].x, p[v].y, p[v].z, 0.0f);
       tn[v] = make_float4(nn.x, nn.y, nn.z, 0.0f);
     }
@@ -640,11 +665,11 @@ __global__ __launch_bounds__(BLK) void k_refit_local(const float* __restrict__ p
       tri_pre[3 * (size_t)j + 2] = make_float4(e2.x, e2.y, e2.z, ng.z);
     }
     if (texcoords) {                                   // surface record (rtcore.h "material / texture shading"), as k_gather_uv
+      const uint4 rc = rec[2];
       const float2* tc = reinterpret_cast<const float2*>(texcoords);
-      const float2 a = tc[tex_idx[3 * (size_t)ti + 0]], b = tc[tex_idx[3 * (size_t)ti + 1]], c = tc[tex_idx[3 * (size_t)ti + 2]];
-      const int32_t m = material_ids ? material_ids[ti] : -1;
+      const float2 a = tc[rb.z], b = tc[rb.w], c = tc[rc.x];
       tri_uv[2 * (size_t)j + 0] = make_float4(a.x, a.y, b.x, b.y);
-      tri_uv[2 * (size_t)j + 1] = make_float4(c.x, c.y, __uint_as_float((uint32_t)m), 0.0f);
+      tri_uv[2 * (size_t)j + 1] = make_float4(c.x, c.y, __uint_as_float(rc.y), 0.0f);
     }
     // true triangle bounds (web/script.js:309-316)
     mn = v3(fminf(fminf(p[0].x, p[1].x), p[2].x), fminf(fminf(p[0].y, p[1].y), p[2].y), fminf(fminf(p[0].z, p[1].z), p[2].z));
@@ -937,6 +962,11 @@ void rt_launch_bounds(const RtBuildBuffers& b, hipStream_t s) {
   hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(384), 0, s, b.bounds_enc, (uint32_t)g, b.bounds_f, b.hist, b.tile_counter);
 }
 
+void rt_launch_interleave(const uint32_t* vidx, const uint32_t* nidx, const uint32_t* tex_idx, const int32_t* material_ids, uint32_t n_tri,
+                          uint4* tri_rec, hipStream_t s) {
+  hipLaunchKernelGGL(k_interleave, dim3((n_tri + BLK - 1) / BLK), dim3(BLK), 0, s, vidx, nidx, tex_idx, material_ids, n_tri, tri_rec);
+}
+
 void rt_launch_morton(const RtBuildBuffers& b, hipStream_t s) {
   // few, fat blocks: every block flushes its LDS digit histograms with one global atomic per non-empty bin
   hipLaunchKernelGGL(k_morton, dim3(grid_for(b.n_tri, BLK * 16, 512)), dim3(BLK), 0, s, b.centroids, b.n_tri, b.bounds_f, b.codes,
@@ -993,8 +1023,8 @@ RefitTables refit_tables(const RtBuildBuffers& b) {
 void rt_launch_refit_local(const RtBuildBuffers& b, float* nodes, float* tri_pos, float* tri_nor, float4* wide, float4* tri_pre, bool v2,
                            hipStream_t s) {
   const RefitTables t = refit_tables(b);
-  hipLaunchKernelGGL(k_refit_local, dim3(t.nb), dim3(BLK), 0, s, b.pos, b.nor, b.vidx, b.nidx, b.vals_a, b.keys_a, b.n_tri, b.span,
-                     nodes, tri_pos, tri_nor, wide, tri_pre, b.texcoords, b.tex_idx, b.material_ids, b.tri_uv, t.mini_box, t.chunk_box,
+  hipLaunchKernelGGL(k_refit_local, dim3(t.nb), dim3(BLK), 0, s, b.pos, b.nor, b.tri_rec, b.vals_a, b.keys_a, b.n_tri, b.span,
+                     nodes, tri_pos, tri_nor, wide, tri_pre, b.texcoords, b.tri_uv, t.mini_box, t.chunk_box,
                      t.block_key, b.tile_counter + 32, b.cross_list, rt_cross_capacity(b.n_tri), v2);
 }
 
