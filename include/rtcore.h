@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2   /* 2: rt_render_stats.pixels_traced, rt_render_device_noalloc, cache-file trailer */
+#define RT_ABI_VERSION 3   /* 2: rt_render_stats.pixels_traced, rt_render_device_noalloc, cache-file trailer; 3: rt_render_batch_device */
 
 enum {
   RT_OK = 0,
@@ -236,6 +236,20 @@ uint32_t rt_packed_rows(uint32_t height, int32_t stripe_rows, int32_t stripe_ran
  * streams - race; serialise them. */
 int rt_render_device_noalloc(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* opts,
                              void* d_rgba8, void* d_hit_tri, void* d_hit_t);
+/* n_frames (1 .. RT_MAX_BATCH) frames of ONE image shape in one pipeline: what the reference does as n_frames successive
+ * frame() calls (script.js:865-945: writeBuffer(uniformBuf) + dispatchWorkgroups per animation frame) - e.g. the next
+ * frames of a camera path, or the same frame's successive PT time seeds.  uniforms = n_frames x 44 floats; every frame
+ * must carry the same resolution (RT_ERR_INVALID otherwise); opts (mode, sample counts, striping, layout, flags) apply to
+ * all of them.  d_rgba8 / d_hit_tri / d_hit_t are HOST arrays of n_frames device pointers (an array, or single entries,
+ * may be NULL); frame f's outputs are exactly those of rt_render_device(uniforms + 44 f, ...), bit for bit.  The frames'
+ * cull and compaction passes run as one launch each and ONE persistent traversal launch drains all the frames' pixel
+ * lists (the hottest pixels of every frame first), so the launch overheads and the idle tail of a frame are paid once
+ * per batch: this is the entry point for small frames / stripe shares (a 1/8 share of a 4K frame is ~0.1 ms of work).
+ * RT_MODE_PRIMARY / SHADOW / PT only (PT runs one lane per pixel); no statistics (RT_FLAG_COUNT_WORK is refused);
+ * asynchronous on rt_stream(); the scheduling hints left behind are those of the last frame. */
+#define RT_MAX_BATCH 8
+int rt_render_batch_device(rt_ctx* ctx, uint32_t n_frames, const float* uniforms /* [n_frames][44] */, const rt_render_opts* opts,
+                           void* const* d_rgba8, void* const* d_hit_tri, void* const* d_hit_t);
 /* De-interleave `world` packed stripe buffers (concatenated rank-major, each
  * rows_per_rank x width x elem_bytes) into a full image; all pointers are device memory. */
 int rt_deinterleave_device(rt_ctx* ctx, const void* d_packed, void* d_image, uint32_t width, uint32_t height,

@@ -298,6 +298,20 @@ class Context:
         self._chk(_L.rt_render_device_noalloc(self._h, _vp(U), C.byref(opts), C.c_void_p(d_rgba8 or None),
                                               C.c_void_p(d_hit_tri or None), C.c_void_p(d_hit_t or None)))
 
+    def render_batch_device(self, uniforms, opts, d_rgba8=None, d_hit_tri=None, d_hit_t=None):
+        """Several frames of one image shape in one pipeline (rt_render_batch_device).  uniforms: [n, 44]; each output
+        argument: a sequence of n device addresses (0 = no such output for that frame) or None; asynchronous."""
+        U = np.ascontiguousarray(uniforms, np.float32).reshape(-1, 44)
+        n = U.shape[0]
+
+        def ptrs(a):
+            if a is None:
+                return None
+            if len(a) != n:
+                raise ValueError("one device address per frame")
+            return (C.c_void_p * n)(*[C.c_void_p(int(x) or None) for x in a])
+        self._chk(_L.rt_render_batch_device(self._h, n, _vp(U), C.byref(opts), ptrs(d_rgba8), ptrs(d_hit_tri), ptrs(d_hit_t)))
+
     def deinterleave_device(self, d_packed, d_image, width, height, elem_bytes, stripe_rows, world, rows_per_rank):
         self._chk(_L.rt_deinterleave_device(self._h, C.c_void_p(d_packed), C.c_void_p(d_image), width, height, elem_bytes,
                                             stripe_rows, world, rows_per_rank))

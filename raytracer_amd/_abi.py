@@ -31,6 +31,7 @@ SYMBOLS = [
     "rt_set_surface", "rt_get_tri_uv", "rt_set_tri_uv", "rt_set_materials", "rt_set_texture", "rt_tri_uv_device",
     "rt_adopt_tri_uv_device", "rt_tri_uv_export_device", "rt_set_frames_in_flight", "rt_frames_join", "rt_set_coherent_scheduling",
     "rt_render_device_noalloc",
+    "rt_render_batch_device",
 ]
 
 
@@ -142,6 +143,7 @@ def load():
         "rt_render": (C.c_int, [vp, vp, C.POINTER(RenderOpts), vp, vp, vp, C.POINTER(RenderStats)]),
         "rt_render_device": (C.c_int, [vp, vp, C.POINTER(RenderOpts), vp, vp, vp, C.POINTER(RenderStats)]),
         "rt_render_device_noalloc": (C.c_int, [vp, vp, C.POINTER(RenderOpts), vp, vp, vp]),
+        "rt_render_batch_device": (C.c_int, [vp, C.c_uint32, vp, C.POINTER(RenderOpts), vp, vp, vp]),
         "rt_packed_rows": (u32, [u32, i32, i32, i32]),
         "rt_deinterleave_device": (C.c_int, [vp, vp, vp, u32, u32, u32, i32, i32, u32]),
         "rt_bvh_view_get": (C.c_int, [vp, C.POINTER(BvhView)]),

@@ -816,6 +816,67 @@ int check_opts(rt_ctx* ctx, const rt_render_opts* o) {
 }  // namespace
 
 namespace {
+// frame-coherent scheduling hints: one cost class per pixel of this image shape, cleared whenever the shape, the
+// striping or the BVH changes (hints of another view are merely useless, never wrong: they only order the work)
+// `moved`: the view differs from the last frame's (or, in a batch, between the batch's frames).
+int setup_hints(rt_ctx* ctx, RtRenderParams& p, const rt_render_opts* opts, bool moved, int slot, hipStream_t s) {
+  const uint64_t key = ((uint64_t)p.width << 40) ^ ((uint64_t)p.local_rows << 20) ^ ((uint64_t)p.stripe_rank << 8) ^ (uint64_t)p.stripe_world ^
+                       ((uint64_t)ctx->bvh_serial << 52);
+  const size_t n_px = (size_t)p.local_rows * p.width;
+  if (key != ctx->pix_class_key || ctx->pix_class.n < n_px) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));   // frames in flight may still use the old array
+    for (int k = 0; k < rt_ctx::MAX_FIF; ++k) if (ctx->fstream[k]) HIPCHK(hipStreamSynchronize(ctx->fstream[k]));
+    HIPCHK(ctx->pix_class.ensure(n_px));
+    HIPCHK(hipMemsetAsync(ctx->pix_class.p, 0, n_px, s));
+    for (bool& r : ctx->class_partial_reset) r = true;
+    ctx->pix_class_key = key;
+  }
+  if (ctx->class_partial_reset[slot]) {
+    HIPCHK(hipMemsetAsync(p.class_hist, 0, sizeof(uint32_t) * 64, s));
+    ctx->class_partial_reset[slot] = false;
+  }
+  p.pix_class = ctx->pix_class.p;
+  // traversal steps per pixel: a ray that only crosses the root box takes a handful, a hit a few dozen
+  // (cfg 3: ~6 / ~40, grazing rays up to 185).  A fixed t2 is scene-dependent (cfg 3 best at 40 steps: 0.523 -> 0.387 ms, 32: 0.47,
+  // 48: 0.41, 64: 0.43; cfg 5 best at 80), so the hot threshold follows last frame's step histogram instead.
+  // PT pixels are a chain of ~50 traversals whatever their class: only hit / miss is separated there.
+  p.class_t1 = 16u;
+  p.class_t2 = ((opts->mode == RT_MODE_PT && !p.pt_cap) || p.frag) ? 0xFFFFFFFFu : 0u;   // 0 = adaptive: the top class_hot_pct % of last frame's non-cheap pixels
+  // A view that changed since the last frame moves the long rays by a few pixels: then a hot pixel promotes its 8x8
+  // tile's non-cheap pixels and the hot share is smaller (tools/moving_camera.py, k_render with / without hints:
+  // static view 0.397 vs 0.463 ms per-pixel, 0.414 promoted; model turning 0.25 deg per frame: per-pixel 0.462 = no
+  // gain, promoted 0.438 = +6 %; 1 deg: +7 %; 4-15 deg: +2 %).  An unchanged view (what the reference redraws all the
+  // time, script.js:865-974) keeps the sharper per-pixel classes: cfg 5 loses its whole gain when promoted (3.19 vs 3.51 ms).
+  p.class_promote = moved ? 1u : 0u;
+  if (const char* e = std::getenv("RTCORE_TILE_PROMOTE")) p.class_promote = (uint32_t)std::atoi(e);
+  p.class_hot_pct = moved ? 10u : 20u;    // unpromoted, static view: 20 / 30 / 40 / 50 % -> k_render 0.394 / 0.415 / 0.394 / 0.451 ms (cfg 3), 3.20 / 3.21 / 3.23 / 3.27 ms (cfg 5)
+  if (const char* e = std::getenv("RTCORE_HOT_PCT")) p.class_hot_pct = (uint32_t)std::atoll(e);
+  {   // quantile bands of the non-cheap pixels, hottest last: with 5 classes the top 50 / 25 / 10 %
+    const uint32_t n_hot = rt_n_class() - 2u;
+    static const uint32_t shares[7][6] = {{0}, {20}, {35, 20}, {45, 25, 12}, {60, 40, 20, 8}, {65, 45, 30, 15, 6}, {70, 50, 35, 22, 12, 5}};
+    for (uint32_t k = 0; k < 6; ++k) p.class_share[k] = k < n_hot ? shares[n_hot][k] : 0u;
+    // Measured with 4 classes (k_render, one box, 3-class build beside it): cfg 3 0.388 vs 0.426 ms, cfg 5 3.08 vs 3.17,
+    // S70k 4K 0.375 vs 0.381, 8-copy lattice 0.620 vs 0.625, S70k 1080p 0.222 vs 0.215 (the one loss).  The landscape is
+    // jumpy: {40,15} is as good on cfg 3 but 12 % worse on S70k 1080p, {25,8} and {50,20} lose most of the gain.
+    // PT part 1 keeps ONE hot class: the order of its records is also the order k_pt_samples walks them in, and finer
+    // classes there cost 4 % (4.03 vs 3.86 ms).
+    if (n_hot == 1 || std::getenv("RTCORE_HOT_PCT") || opts->mode == RT_MODE_PT) {
+      p.class_share[0] = p.class_hot_pct;
+      for (uint32_t k = 1; k < 6; ++k) p.class_share[k] = 0u;      // share 0: the class stays empty
+    }
+    else if (moved) for (uint32_t k = 0; k < n_hot; ++k) p.class_share[k] = (p.class_share[k] + 1u) / 2u;
+    if (const char* e = std::getenv("RTCORE_CLASS_SHARES")) {   // e.g. "50,25,10"
+      uint32_t k = 0;
+      for (const char* q = e; *q && k < n_hot; ++k) { p.class_share[k] = (uint32_t)std::strtoul(q, const_cast<char**>(&q), 10); if (*q == ',') ++q; }
+    }
+  }
+  if (const char* e = std::getenv("RTCORE_T1")) p.class_t1 = (uint32_t)std::atoll(e);
+  if (const char* e = std::getenv("RTCORE_T2")) p.class_t2 = (uint32_t)std::atoll(e);
+  return RT_OK;
+}
+}  // namespace
+
+namespace {
 // One frame.  noalloc = false: rt_render_device (scratch in lazily grown per-frame-slot allocations).  noalloc = true:
 // rt_render_device_noalloc - the same kernels with this GPU's static scratch array carved up instead; no hipMalloc /
 // hipFree anywhere on the path, hence no frame slots (the array is one per GPU), no scheduling hints, no PT split, no stats.
@@ -902,7 +963,9 @@ int render_frame(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* op
     sc_tc = reinterpret_cast<uint32_t*>(ctx->noalloc_scratch + NOALLOC_OFF_TC);
   } else {
     HIPCHK(ctx->r_tile_counter[slot].ensure(tc_words));
+    const unsigned long long* st_before = ctx->r_stats[slot].p;
     HIPCHK(ctx->r_stats[slot].ensure(st_words));
+    if (ctx->r_stats[slot].p != st_before) ctx->class_partial_reset[slot] = true;   // the step histogram lives there
     HIPCHK(ctx->r_list[slot].ensure(list_words));
     sc_tc = ctx->r_tile_counter[slot].p; sc_st = ctx->r_stats[slot].p; sc_list = ctx->r_list[slot].p;
   }
@@ -938,63 +1001,11 @@ int render_frame(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* op
   p.stats = sc_st; p.stats_partial = sc_st + 8 + 32;
   p.class_hist = reinterpret_cast<uint32_t*>(sc_st + 8);   // 64 u32
   p.masks = sc_st + 8 + 32 + (size_t)rt_render_grid(ctx->n_cu) * 8;
-  // frame-coherent scheduling hints: one cost class per pixel of this image shape, cleared whenever the shape, the
-  // striping or the BVH changes (hints of another view are merely useless, never wrong: they only order the work)
   if (ctx->coherent_scheduling && !noalloc) {
-    const uint64_t key = ((uint64_t)p.width << 40) ^ ((uint64_t)p.local_rows << 20) ^ ((uint64_t)p.stripe_rank << 8) ^ (uint64_t)p.stripe_world ^
-                         ((uint64_t)ctx->bvh_serial << 52);
-    const size_t n_px = (size_t)p.local_rows * p.width;
-    if (key != ctx->pix_class_key || ctx->pix_class.n < n_px) {
-      HIPCHK(hipStreamSynchronize(ctx->stream));   // frames in flight may still use the old array
-      for (int k = 0; k < rt_ctx::MAX_FIF; ++k) if (ctx->fstream[k]) HIPCHK(hipStreamSynchronize(ctx->fstream[k]));
-      HIPCHK(ctx->pix_class.ensure(n_px));
-      HIPCHK(hipMemsetAsync(ctx->pix_class.p, 0, n_px, s));
-      for (bool& r : ctx->class_partial_reset) r = true;
-      ctx->pix_class_key = key;
-    }
-    if (ctx->class_partial_reset[slot]) {
-      HIPCHK(hipMemsetAsync(p.class_hist, 0, sizeof(uint32_t) * 64, s));
-      ctx->class_partial_reset[slot] = false;
-    }
-    p.pix_class = ctx->pix_class.p;
-    // traversal steps per pixel: a ray that only crosses the root box takes a handful, a hit a few dozen
-    // (cfg 3: ~6 / ~40, grazing rays up to 185).  A fixed t2 is scene-dependent (cfg 3 best at 40 steps: 0.523 -> 0.387 ms, 32: 0.47,
-    // 48: 0.41, 64: 0.43; cfg 5 best at 80), so the hot threshold follows last frame's step histogram instead.
-    // PT pixels are a chain of ~50 traversals whatever their class: only hit / miss is separated there.
-    p.class_t1 = 16u;
-    p.class_t2 = ((opts->mode == RT_MODE_PT && !p.pt_cap) || p.frag) ? 0xFFFFFFFFu : 0u;   // 0 = adaptive: the top class_hot_pct % of last frame's non-cheap pixels
-    // A view that changed since the last frame moves the long rays by a few pixels: then a hot pixel promotes its 8x8
-    // tile's non-cheap pixels and the hot share is smaller (tools/moving_camera.py, k_render with / without hints:
-    // static view 0.397 vs 0.463 ms per-pixel, 0.414 promoted; model turning 0.25 deg per frame: per-pixel 0.462 = no
-    // gain, promoted 0.438 = +6 %; 1 deg: +7 %; 4-15 deg: +2 %).  An unchanged view (what the reference redraws all the
-    // time, script.js:865-974) keeps the sharper per-pixel classes: cfg 5 loses its whole gain when promoted (3.19 vs 3.51 ms).
     const bool moved = std::memcmp(ctx->last_uniforms, uniforms, sizeof(float) * 44) != 0;
     std::memcpy(ctx->last_uniforms, uniforms, sizeof(float) * 44);
-    p.class_promote = moved ? 1u : 0u;
-    if (const char* e = std::getenv("RTCORE_TILE_PROMOTE")) p.class_promote = (uint32_t)std::atoi(e);
-    p.class_hot_pct = moved ? 10u : 20u;    // unpromoted, static view: 20 / 30 / 40 / 50 % -> k_render 0.394 / 0.415 / 0.394 / 0.451 ms (cfg 3), 3.20 / 3.21 / 3.23 / 3.27 ms (cfg 5)
-    if (const char* e = std::getenv("RTCORE_HOT_PCT")) p.class_hot_pct = (uint32_t)std::atoll(e);
-    {   // quantile bands of the non-cheap pixels, hottest last: with 5 classes the top 50 / 25 / 10 %
-      const uint32_t n_hot = rt_n_class() - 2u;
-      static const uint32_t shares[7][6] = {{0}, {20}, {35, 20}, {45, 25, 12}, {60, 40, 20, 8}, {65, 45, 30, 15, 6}, {70, 50, 35, 22, 12, 5}};
-      for (uint32_t k = 0; k < 6; ++k) p.class_share[k] = k < n_hot ? shares[n_hot][k] : 0u;
-      // Measured with 4 classes (k_render, one box, 3-class build beside it): cfg 3 0.388 vs 0.426 ms, cfg 5 3.08 vs 3.17,
-      // S70k 4K 0.375 vs 0.381, 8-copy lattice 0.620 vs 0.625, S70k 1080p 0.222 vs 0.215 (the one loss).  The landscape is
-      // jumpy: {40,15} is as good on cfg 3 but 12 % worse on S70k 1080p, {25,8} and {50,20} lose most of the gain.
-      // PT part 1 keeps ONE hot class: the order of its records is also the order k_pt_samples walks them in, and finer
-      // classes there cost 4 % (4.03 vs 3.86 ms).
-      if (n_hot == 1 || std::getenv("RTCORE_HOT_PCT") || opts->mode == RT_MODE_PT) {
-        p.class_share[0] = p.class_hot_pct;
-        for (uint32_t k = 1; k < 6; ++k) p.class_share[k] = 0u;      // share 0: the class stays empty
-      }
-      else if (moved) for (uint32_t k = 0; k < n_hot; ++k) p.class_share[k] = (p.class_share[k] + 1u) / 2u;
-      if (const char* e = std::getenv("RTCORE_CLASS_SHARES")) {   // e.g. "50,25,10"
-        uint32_t k = 0;
-        for (const char* q = e; *q && k < n_hot; ++k) { p.class_share[k] = (uint32_t)std::strtoul(q, const_cast<char**>(&q), 10); if (*q == ',') ++q; }
-      }
-    }
-    if (const char* e = std::getenv("RTCORE_T1")) p.class_t1 = (uint32_t)std::atoll(e);
-    if (const char* e = std::getenv("RTCORE_T2")) p.class_t2 = (uint32_t)std::atoll(e);
+    rc = setup_hints(ctx, p, opts, moved, slot, s);
+    if (rc != RT_OK) return rc;
   }
   rt_cull_rect(p, ctx->bvh.root_box);
   if (p.frag) {   // the fragment shaders' screen y runs the other way (uv.y = 1 - (gy + 0.5) / h): the same rectangle, rows mirrored
@@ -1034,6 +1045,116 @@ int render_frame(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* op
 }
 }  // namespace
 
+namespace {
+// A batch of frames of one image shape (rt_render_batch_device): the frames' k_cull / k_compact passes run as the y
+// dimension of two launches and ONE persistent k_render drains all their pixel lists, hottest classes of every frame
+// first - the tail of one frame is filled by the next frame's pixels instead of idling the chip, and the three launches'
+// fixed cost is paid once.  Same per-pixel code as render_frame, hence the same bytes.
+int render_batch(rt_ctx* ctx, uint32_t n_frames, const float* uniforms, const rt_render_opts* opts, void* const* d_rgba8,
+                 void* const* d_hit_tri, void* const* d_hit_t) {
+  NEED_BVH();
+  if (n_frames < 1 || n_frames > (uint32_t)RT_MAX_BATCH) return ctx->fail(RT_ERR_INVALID, "rt_render_batch_device: n_frames must be in [1, " + std::to_string(RT_MAX_BATCH) + "]");
+  if (!uniforms) return ctx->fail(RT_ERR_INVALID, "uniforms are NULL");
+  int rc = check_opts(ctx, opts);
+  if (rc != RT_OK) return rc;
+  if (opts->mode > RT_MODE_PT) return ctx->fail(RT_ERR_INVALID, "rt_render_batch_device: RT_MODE_PRIMARY / SHADOW / PT only");
+  if (opts->flags & RT_FLAG_COUNT_WORK) return ctx->fail(RT_ERR_INVALID, "rt_render_batch_device keeps no statistics: RT_FLAG_COUNT_WORK is not defined for it");
+  const float fw = uniforms[36], fh = uniforms[37];
+  if (!(fw >= 1.0f) || !(fh >= 1.0f) || fw > 65536.0f || fh > 65536.0f) return ctx->fail(RT_ERR_INVALID, "resolution out of range");
+  RtBatch bt;
+  std::memset(&bt, 0, sizeof(bt));
+  bt.n = n_frames;
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    const float* U = uniforms + 44 * (size_t)f;
+    if (U[36] != fw || U[37] != fh) return ctx->fail(RT_ERR_INVALID, "rt_render_batch_device: every frame of a batch has the same resolution (frame " + std::to_string(f) + " differs)");
+    void* o[3] = {d_rgba8 ? d_rgba8[f] : nullptr, d_hit_tri ? d_hit_tri[f] : nullptr, d_hit_t ? d_hit_t[f] : nullptr};
+    if (((reinterpret_cast<uintptr_t>(o[0]) | reinterpret_cast<uintptr_t>(o[1]) | reinterpret_cast<uintptr_t>(o[2])) & 3u) != 0u)
+      return ctx->fail(RT_ERR_INVALID, "output pointers must be 4-byte aligned");
+    std::memcpy(bt.U[f], U, sizeof(float) * 44);
+    bt.rgba8[f] = static_cast<uint8_t*>(o[0]); bt.hit_tri[f] = static_cast<uint32_t*>(o[1]); bt.hit_t[f] = static_cast<float*>(o[2]);
+  }
+  DeviceGuard g(ctx->device);
+  RtRenderParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.nodes = ctx->bvh.nodes; p.tri_pos = ctx->bvh.tri_pos; p.tri_nor = ctx->bvh.tri_nor;
+  p.wide = ctx->bvh.wide; p.tri_pre = ctx->bvh.tri_pre; p.root_ref = ctx->bvh.root_ref; p.leaf_shift = ctx->bvh.leaf_shift;
+  p.nodes_v2 = ctx->bvh.v2 ? 1 : 0;
+  p.step_budget = ctx->bvh.n_nodes + ctx->bvh.n_tri + 64u;      // as render_frame
+  if (opts->flags & RT_FLAG_TEXTURED) {
+    if (ctx->tri_uv_n == 0 || ctx->tri_uv_n != ctx->bvh.n_tri)
+      return ctx->fail(RT_ERR_INVALID, "RT_FLAG_TEXTURED: no surface records for the current BVH (rt_set_surface before rt_build_lbvh, or rt_set_tri_uv)");
+    for (uint32_t i = 0; i < ctx->n_materials; ++i) {
+      const int32_t t = ctx->materials_host[i].texture;
+      if (t >= 0 && ((uint32_t)t >= ctx->n_textures || ctx->tex_host[t].texels == nullptr))
+        return ctx->fail(RT_ERR_INVALID, "RT_FLAG_TEXTURED: material " + std::to_string(i) + " names texture slot " + std::to_string(t) + ", which was never set");
+    }
+    HIPCHK(ctx->materials.ensure(1)); HIPCHK(ctx->tex_table.ensure(RT_MAX_TEXTURES));
+    p.tri_uv = reinterpret_cast<const float4*>(ctx->tri_uv.p); p.materials = ctx->materials.p; p.textures = ctx->tex_table.p;
+    p.n_materials = ctx->n_materials; p.n_textures = ctx->n_textures;
+  }
+  std::memcpy(p.U, uniforms, sizeof(float) * 44);               // (the kernels of a batch read bt.U[f])
+  p.mode = opts->mode; p.gi_samples = opts->gi_samples; p.gi_bounces = opts->gi_bounces; p.soft_samples = opts->soft_samples;
+  p.max_stack = opts->max_stack;
+  p.miss_rgba = 0xFF000000u;
+  p.width = (uint32_t)fw; p.height = (uint32_t)fh;
+  const bool striped = opts->stripe_rows > 0 && opts->stripe_world > 1;
+  p.stripe_rows = striped ? opts->stripe_rows : 0; p.stripe_rank = striped ? opts->stripe_rank : 0;
+  p.stripe_world = striped ? opts->stripe_world : 1;
+  p.local_rows = rt_packed_rows(p.height, p.stripe_rows, p.stripe_rank, p.stripe_world);
+  p.tiles_x = (p.width + 7) / 8;
+  p.n_tiles = p.tiles_x * ((p.local_rows + 7) / 8);
+  if (p.n_tiles == 0) return RT_OK;                             // this rank owns no rows
+  const uint32_t cull_blocks = rt_cull_blocks(p.n_tiles);
+  JOIN_FRAMES();
+  hipStream_t s = ctx->stream;
+  const int slot = 0;
+  const size_t list_words = ((size_t)p.local_rows * p.width + 63u) & ~(size_t)63u;
+  bt.mask_stride = rt_n_class() * p.n_tiles;
+  bt.bt_stride = rt_n_class() * cull_blocks;
+  bt.list_stride = (uint32_t)list_words;
+  bt.lc_stride = RT_LC_WORDS;
+  if (list_words * n_frames > 0xFFFFFFFFull) return ctx->fail(RT_ERR_LIMIT, "rt_render_batch_device: the batch's pixel lists exceed 2^32 entries");
+  const size_t tc_words = (size_t)rt_shard_words() + (size_t)RT_LC_WORDS * n_frames + (size_t)bt.bt_stride * n_frames;
+  const size_t st_words = 8 + 32 + (size_t)bt.mask_stride * n_frames;
+  HIPCHK(ctx->r_tile_counter[slot].ensure(tc_words));
+  const unsigned long long* st_before = ctx->r_stats[slot].p;
+  HIPCHK(ctx->r_stats[slot].ensure(st_words));
+  if (ctx->r_stats[slot].p != st_before) ctx->class_partial_reset[slot] = true;
+  HIPCHK(ctx->r_list[slot].ensure(list_words * n_frames));
+  uint32_t* sc_tc = ctx->r_tile_counter[slot].p;
+  unsigned long long* sc_st = ctx->r_stats[slot].p;
+  p.shard_stride = rt_shard_stride();
+  p.shard_group = 8;
+  if (const char* e = std::getenv("RTCORE_SHARD_GROUP")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) p.shard_group = (uint32_t)v; }
+  p.shard_heads = sc_tc; p.list_count = sc_tc + rt_shard_words();
+  p.block_total = p.list_count + (size_t)RT_LC_WORDS * n_frames;
+  p.list = ctx->r_list[slot].p;
+  p.stats = sc_st;
+  p.class_hist = reinterpret_cast<uint32_t*>(sc_st + 8);        // where render_frame keeps it: single frames and batches share the history
+  p.masks = sc_st + 8 + 32;
+  if (ctx->coherent_scheduling) {
+    bool moved = std::memcmp(ctx->last_uniforms, uniforms, sizeof(float) * 44) != 0;
+    for (uint32_t f = 1; f < n_frames; ++f) moved = moved || std::memcmp(uniforms, uniforms + 44 * (size_t)f, sizeof(float) * 44) != 0;
+    std::memcpy(ctx->last_uniforms, uniforms + 44 * (size_t)(n_frames - 1), sizeof(float) * 44);
+    rc = setup_hints(ctx, p, opts, moved, slot, s);
+    if (rc != RT_OK) return rc;
+  }
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    RtRenderParams pf = p;
+    std::memcpy(pf.U, bt.U[f], sizeof(float) * 44);
+    rt_cull_rect(pf, ctx->bvh.root_box);
+    bt.cull[f][0] = pf.cull_x0; bt.cull[f][1] = pf.cull_x1; bt.cull[f][2] = pf.cull_y0; bt.cull[f][3] = pf.cull_y1;
+  }
+  hipEvent_t* E = nullptr;   // {batch begin, k_render begin, k_render end, batch end}: rt_profile_end reports per batch
+  if (ctx->prof_on) { E = &ctx->prof_ev[4 * (size_t)(ctx->prof_n % rt_ctx::PROF_RING)]; ctx->prof_n += 1; }
+  if (E) HIPCHK(hipEventRecord(E[0], s));
+  rt_launch_render_batch(p, bt, opts->layout, ctx->n_cu, s, E ? E[1] : nullptr, E ? E[2] : nullptr);
+  HIPCHK(hipGetLastError());
+  if (E) HIPCHK(hipEventRecord(E[3], s));
+  return RT_OK;
+}
+}  // namespace
+
 extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* opts, void* d_rgba8, void* d_hit_tri,
                                 void* d_hit_t, rt_render_stats* out) {
   return render_frame(ctx, uniforms, opts, d_rgba8, d_hit_tri, d_hit_t, out, /*noalloc=*/false);
@@ -1043,6 +1164,12 @@ extern "C" int rt_render_device(rt_ctx* ctx, const float uniforms[44], const rt_
 extern "C" int rt_render_device_noalloc(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* opts, void* d_rgba8,
                                         void* d_hit_tri, void* d_hit_t) {
   return render_frame(ctx, uniforms, opts, d_rgba8, d_hit_tri, d_hit_t, nullptr, /*noalloc=*/true);
+}
+
+extern "C" int rt_render_batch_device(rt_ctx* ctx, uint32_t n_frames, const float* uniforms, const rt_render_opts* opts,
+                                      void* const* d_rgba8, void* const* d_hit_tri, void* const* d_hit_t) {
+  if (!ctx) return RT_ERR_INVALID;
+  return render_batch(ctx, n_frames, uniforms, opts, d_rgba8, d_hit_tri, d_hit_t);
 }
 
 extern "C" int rt_set_coherent_scheduling(rt_ctx* ctx, int on) {

@@ -94,6 +94,25 @@ struct RtRenderParams {
   unsigned long long* stats_partial;   // [rt_render_grid()*8] per-block partials of phase B
 };
 
+// Several frames of one shape in one frame pipeline (rt_render_batch_device): k_cull / k_compact run with the frame as
+// grid.y over per-frame scratch regions, ONE persistent k_render walks all the frames' pixel lists, hottest class of every
+// frame first.  Passed by value next to RtRenderParams (whose U / outputs / cull rectangle are then unused).
+struct RtBatch {
+  uint32_t n;
+  uint32_t mask_stride;      // u64 words between the frames' tile-mask arrays
+  uint32_t bt_stride;        // u32 words between the frames' block totals
+  uint32_t list_stride;      // u32 words between the frames' pixel lists
+  uint32_t lc_stride;        // u32 words between the frames' list_count blocks
+  float     U[RT_MAX_BATCH][44];
+  uint8_t*  rgba8[RT_MAX_BATCH];
+  uint32_t* hit_tri[RT_MAX_BATCH];
+  float*    hit_t[RT_MAX_BATCH];
+  int       cull[RT_MAX_BATCH][4];   // x0, x1, y0, y1 per frame
+};
+struct RtNoBatch {};
+constexpr uint32_t RT_LC_WORDS = 32;   // list_count block of a frame: [0] entries, [1] hottest-class entries, [2..7] class thresholds,
+                                       // [8 + c] start of class c in the list, [16 + c] entries of class c
+
 // ---------------------------------------------------------------- build pipeline (rt_build.hip)
 struct RtBuildBuffers {
   const float* pos; const float* nor; const uint32_t* vidx; const uint32_t* nidx;
@@ -152,6 +171,9 @@ uint32_t rt_shard_stride();
 // p.tri_uv != NULL selects the textured instantiation
 void rt_launch_render(const RtRenderParams& p, int layout, bool count_work, bool want_stats, int n_cu, hipStream_t s,
                       hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+// the same pipeline over bt.n frames (no stats, no PT split, compute.wgsl modes only)
+void rt_launch_render_batch(const RtRenderParams& p, const RtBatch& bt, int layout, int n_cu, hipStream_t s,
+                            hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 // BVH-order surface records: record i <- input triangle order[i]
 void rt_launch_gather_uv(const float* texcoords, const uint32_t* tex_idx, const int32_t* material_ids, const uint32_t* order,
                          uint32_t n_tri, float* tri_uv, hipStream_t s);

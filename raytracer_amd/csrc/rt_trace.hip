@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 
 #include "rt_device.h"
 #include "rt_internal.h"
@@ -717,38 +718,61 @@ static int shard_stride_words() { return SHARD_STRIDE; }
 //   level 2, lane = one 8-pixel ROW of a tile (a wave covers 8 tiles): the ray test only in silhouette tiles; last
 //     frame's 8 cost classes of the row are one 8-byte load.  The row's 8-bit masks (entering pixels by class) are bytes
 //     of the tile's 64-bit masks in LDS — bit 8 * row + x, the order k_compact and k_render expect.
-RT_DEV void cull_write_miss(const RtRenderParams& p, size_t idx0, uint32_t bits) {
+// What differs between the frames of a batch (rt_render_batch_device); a single frame's view is the RtRenderParams itself.
+struct FrameView {
+  const float* U; uint8_t* rgba8; uint32_t* hit_tri; float* hit_t; int cull_x0, cull_x1, cull_y0, cull_y1;
+  unsigned long long* masks; uint32_t* block_total; uint32_t* list; uint32_t* list_count;
+};
+template <bool BATCH, typename B>
+RT_DEV FrameView frame_view(const RtRenderParams& p, const B& bt, uint32_t f) {
+  FrameView v;
+  if constexpr (BATCH) {
+    v.U = bt.U[f]; v.rgba8 = bt.rgba8[f]; v.hit_tri = bt.hit_tri[f]; v.hit_t = bt.hit_t[f];
+    v.cull_x0 = bt.cull[f][0]; v.cull_x1 = bt.cull[f][1]; v.cull_y0 = bt.cull[f][2]; v.cull_y1 = bt.cull[f][3];
+    v.masks = p.masks + (size_t)f * bt.mask_stride; v.block_total = p.block_total + (size_t)f * bt.bt_stride;
+    v.list = p.list + (size_t)f * bt.list_stride; v.list_count = p.list_count + (size_t)f * bt.lc_stride;
+  } else {
+    v.U = p.U; v.rgba8 = p.rgba8; v.hit_tri = p.hit_tri; v.hit_t = p.hit_t;
+    v.cull_x0 = p.cull_x0; v.cull_x1 = p.cull_x1; v.cull_y0 = p.cull_y0; v.cull_y1 = p.cull_y1;
+    v.masks = p.masks; v.block_total = p.block_total; v.list = p.list; v.list_count = p.list_count;
+  }
+  return v;
+}
+
+RT_DEV void cull_write_miss(const RtRenderParams& p, const FrameView& fv, size_t idx0, uint32_t bits) {
   const bool vec = bits == 0xFFu && (p.width & 3u) == 0u;      // a whole row of a whole tile: 2 x 16-byte stores per output
-  if (p.rgba8) {
-    uint32_t* d = reinterpret_cast<uint32_t*>(p.rgba8) + idx0;
-    if (vec && (reinterpret_cast<uintptr_t>(p.rgba8) & 15u) == 0u) {
+  if (fv.rgba8) {
+    uint32_t* d = reinterpret_cast<uint32_t*>(fv.rgba8) + idx0;
+    if (vec && (reinterpret_cast<uintptr_t>(fv.rgba8) & 15u) == 0u) {
       const uint4 v = make_uint4(p.miss_rgba, p.miss_rgba, p.miss_rgba, p.miss_rgba);
       reinterpret_cast<uint4*>(d)[0] = v; reinterpret_cast<uint4*>(d)[1] = v;
     } else for (int i = 0; i < 8; ++i) if ((bits >> i) & 1u) d[i] = p.miss_rgba;
   }
-  if (p.hit_tri) {
-    uint32_t* d = p.hit_tri + idx0;
-    if (vec && (reinterpret_cast<uintptr_t>(p.hit_tri) & 15u) == 0u) {
+  if (fv.hit_tri) {
+    uint32_t* d = fv.hit_tri + idx0;
+    if (vec && (reinterpret_cast<uintptr_t>(fv.hit_tri) & 15u) == 0u) {
       const uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
       reinterpret_cast<uint4*>(d)[0] = v; reinterpret_cast<uint4*>(d)[1] = v;
     } else for (int i = 0; i < 8; ++i) if ((bits >> i) & 1u) d[i] = 0xFFFFFFFFu;
   }
-  if (p.hit_t) {
-    float* d = p.hit_t + idx0;
-    if (vec && (reinterpret_cast<uintptr_t>(p.hit_t) & 15u) == 0u) {
+  if (fv.hit_t) {
+    float* d = fv.hit_t + idx0;
+    if (vec && (reinterpret_cast<uintptr_t>(fv.hit_t) & 15u) == 0u) {
       const float4 v = make_float4(1e20f, 1e20f, 1e20f, 1e20f);
       reinterpret_cast<float4*>(d)[0] = v; reinterpret_cast<float4*>(d)[1] = v;
     } else for (int i = 0; i < 8; ++i) if ((bits >> i) & 1u) d[i] = 1e20f;
   }
 }
 
-__global__ __launch_bounds__(TBLK) void k_cull(const RtRenderParams p) {
+template <bool BATCH, typename B>
+__global__ __launch_bounds__(TBLK) void k_cull(const RtRenderParams p, const B bt) {
+  const FrameView fv = frame_view<BATCH>(p, bt, BATCH ? blockIdx.y : 0u);
   __shared__ uint8_t s_corner[4][CULL_TPB];
   __shared__ uint32_t s_txy[CULL_TPB];
   __shared__ unsigned long long s_m[N_CLASS][CULL_TPB];      // the block's tile masks; byte r of a mask comes from the lane of tile row r
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float4 ra = reinterpret_cast<const float4*>(p.nodes)[0], rb = reinterpret_cast<const float4*>(p.nodes)[1];
-  if (blockIdx.x == 0)   // phase-B queue heads start at zero (k_render runs two launches later)
+  if (blockIdx.x == 0 && blockIdx.y == 0)   // phase-B queue heads start at zero (k_render runs two launches later)
     for (uint32_t i = threadIdx.x; i < (uint32_t)(N_SHARD * SHARD_STRIDE); i += TBLK) {
       p.shard_heads[i] = 0u;
       if (p.pt_cap) { p.pt_heads[i] = 0u; if (i < (uint32_t)N_SHARD) p.pt_count[i] = 0u; }
@@ -760,9 +784,9 @@ __global__ __launch_bounds__(TBLK) void k_cull(const RtRenderParams p) {
     uint8_t state = 0;                                      // 0 = outside the root box's screen rectangle (or no tile), 1 = corner ray enters, 2 = corner ray misses
     if (tile < p.n_tiles) {
       const int tx0 = (int)(tx * 8u), ty0 = (int)local_to_global_row(p, ty * 8u);   // a tile's 8 rows are contiguous in the image: stripes are multiples of 8 rows
-      const bool tile_in = tx0 <= p.cull_x1 && tx0 + 7 >= p.cull_x0 && ty0 <= p.cull_y1 && ty0 + 7 >= p.cull_y0;
+      const bool tile_in = tx0 <= fv.cull_x1 && tx0 + 7 >= fv.cull_x0 && ty0 <= fv.cull_y1 && ty0 + 7 >= fv.cull_y0;
       if (tile_in) {
-        const PrimaryRay pr = primary_ray(p.U, (uint32_t)tx0 + ((w & 1) ? 7u : 0u), (uint32_t)ty0 + ((w & 2) ? 7u : 0u), p.width, p.height, p.frag);
+        const PrimaryRay pr = primary_ray(fv.U, (uint32_t)tx0 + ((w & 1) ? 7u : 0u), (uint32_t)ty0 + ((w & 2) ? 7u : 0u), p.width, p.height, p.frag);
         float tn, tf; slab(pr.ro, pr.inv, xyz(ra), xyz(rb), tn, tf);
         state = box_hit(tn, tf, 1e20f) ? 1 : 2;
       }
@@ -790,13 +814,13 @@ __global__ __launch_bounds__(TBLK) void k_cull(const RtRenderParams p) {
 #pragma unroll 1
         for (uint32_t i = 0; i < 8u; ++i) {
           if (!((vm >> i) & 1u)) continue;
-          const PrimaryRay pr = primary_ray(p.U, x0 + i, y, p.width, p.height, p.frag);
+          const PrimaryRay pr = primary_ray(fv.U, x0 + i, y, p.width, p.height, p.frag);
           float tn, tf; slab(pr.ro, pr.inv, xyz(ra), xyz(rb), tn, tf);
           if (box_hit(tn, tf, 1e20f)) e |= 1u << i;
         }
       }
       const size_t idx0 = (size_t)lrow * p.width + x0;
-      if (vm & ~e) cull_write_miss(p, idx0, vm & ~e);            // ray / box-test / pixel counts of these: k_stats_final
+      if (vm & ~e) cull_write_miss(p, fv, idx0, vm & ~e);            // ray / box-test / pixel counts of these: k_stats_final
       if (e && p.pix_class) {                                    // last frame's hints; anything else than 1 / 2 counts as 0
         unsigned long long cls = 0ull;
         if ((p.width & 7u) == 0u) cls = *reinterpret_cast<const unsigned long long*>(p.pix_class + idx0);
@@ -837,16 +861,18 @@ __global__ __launch_bounds__(TBLK) void k_cull(const RtRenderParams p) {
   for (int c = w; c < N_CLASS; c += TBLK / 64) {                 // lane = tile: masks out, per-class totals of the block
     const uint32_t tile = blockIdx.x * CULL_TPB + (uint32_t)lane;
     const unsigned long long m = s_m[c][lane];
-    if (tile < p.n_tiles) p.masks[(size_t)tile * N_CLASS + c] = m;
+    if (tile < p.n_tiles) fv.masks[(size_t)tile * N_CLASS + c] = m;
     const uint32_t tot = wave_sum_u32((uint32_t)__popcll(m));
-    if (lane == 0) p.block_total[(size_t)blockIdx.x * N_CLASS + c] = tot;
+    if (lane == 0) fv.block_total[(size_t)blockIdx.x * N_CLASS + c] = tot;
   }
 }
 
 // Phase A2 — compact.  Block b owns the same 64 tiles as in k_cull.  List layout: class-major (hot, normal, cheap); inside
 // a class block-major, tile-major, lane order.  Every offset is a sum of k_cull's per-block per-class totals (a few KB
 // read per block) plus a wave scan of the block's 64 tile popcounts: atomic-free and deterministic.
-__global__ __launch_bounds__(TBLK) void k_compact(const RtRenderParams p) {
+template <bool BATCH, typename B>
+__global__ __launch_bounds__(TBLK) void k_compact(const RtRenderParams p, const B bt) {
+  const FrameView fv = frame_view<BATCH>(p, bt, BATCH ? blockIdx.y : 0u);
   __shared__ uint32_t s_red[TBLK / 64][2 * N_CLASS];
   __shared__ uint32_t s_pref[N_CLASS][CULL_TPB];
   __shared__ uint32_t s_txy[CULL_TPB];
@@ -861,14 +887,14 @@ __global__ __launch_bounds__(TBLK) void k_compact(const RtRenderParams p) {
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
       const int c = w + i * (TBLK / 64);
-      my_mask[i] = (c < N_CLASS && tile < p.n_tiles) ? p.masks[(size_t)tile * N_CLASS + c] : 0ull;
+      my_mask[i] = (c < N_CLASS && tile < p.n_tiles) ? fv.masks[(size_t)tile * N_CLASS + c] : 0ull;
     }
     if (w == TBLK / 64 - 1) s_txy[lane] = (tile % p.tiles_x) | ((tile / p.tiles_x) << 16);   // tile coordinates, once per tile
   }
   for (uint32_t i = threadIdx.x; i < n_blocks; i += TBLK) {
 #pragma unroll
     for (int c = 0; c < N_CLASS; ++c) {
-      const uint32_t t = p.block_total[(size_t)i * N_CLASS + c];
+      const uint32_t t = fv.block_total[(size_t)i * N_CLASS + c];
       all[c] += t;
       if (i < me) mine[c] += t;
     }
@@ -903,9 +929,14 @@ __global__ __launch_bounds__(TBLK) void k_compact(const RtRenderParams p) {
   // list order: hottest class first, cheap / unknown (0) last
   uint32_t base[N_CLASS], above = 0u;
 #pragma unroll
-  for (int c = N_CLASS - 1; c >= 0; --c) { base[c] = above + tot[N_CLASS + c]; above += tot[c]; }
-  if (me == 0 && threadIdx.x == 0) { p.list_count[0] = above; p.list_count[1] = tot[N_CLASS - 1]; }   // all entries, hottest class
-  if (me == 0 && w == TBLK / 64 - 1 && p.pix_class) {   // hot threshold of THIS frame from last frame's step histogram
+  for (int c = N_CLASS - 1; c >= 0; --c) {
+    base[c] = above + tot[N_CLASS + c];
+    if (BATCH && me == 0 && threadIdx.x == 0) { fv.list_count[8 + c] = above; fv.list_count[16 + c] = tot[c]; }   // the class's run in this frame's list
+    above += tot[c];
+  }
+  if (me == 0 && threadIdx.x == 0) { fv.list_count[0] = above; fv.list_count[1] = tot[N_CLASS - 1]; }   // all entries, hottest class
+  // (a batch shares one set of thresholds and one step histogram: frame 0's block derives them)
+  if (me == 0 && w == TBLK / 64 - 1 && p.pix_class && (!BATCH || blockIdx.y == 0)) {   // hot threshold of THIS frame from last frame's step histogram
     // thresholds of classes 2 .. N-1 (list_count[2 ..]): fixed t2 -> one hot class; adaptive -> quantile bands
     uint32_t thr[N_CLASS];
 #pragma unroll
@@ -928,7 +959,7 @@ __global__ __launch_bounds__(TBLK) void k_compact(const RtRenderParams p) {
     if (lane == 0) {
       uint32_t floor_t = p.class_t1 + 1u;                 // thresholds ascend with the class
 #pragma unroll
-      for (int c = 2; c < N_CLASS; ++c) { thr[c] = max(thr[c], floor_t); floor_t = thr[c]; p.list_count[c] = thr[c]; }
+      for (int c = 2; c < N_CLASS; ++c) { thr[c] = max(thr[c], floor_t); floor_t = thr[c]; fv.list_count[c] = thr[c]; }
     }
   }
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -942,7 +973,7 @@ __global__ __launch_bounds__(TBLK) void k_compact(const RtRenderParams p) {
 #pragma unroll
     for (int c = 0; c < N_CLASS; ++c) {
       const unsigned long long m = s_mask[c][k];
-      if ((m >> lane) & 1ull) p.list[base[c] + s_pref[c][k] + (uint32_t)__popcll(m & lt)] = lrow * p.width + x;
+      if ((m >> lane) & 1ull) fv.list[base[c] + s_pref[c][k] + (uint32_t)__popcll(m & lt)] = lrow * p.width + x;
     }
   }
 }
@@ -964,9 +995,10 @@ extern "C" int rt_debug_timeline(unsigned long long* out, size_t n_words) {
 #endif
 
 enum { KIND_PIXEL = 0, KIND_PTSPLIT = 1, KIND_FRAG_WEB = 2, KIND_FRAG_ROOT = 3 };   // what a lane does with its pixel
-template <int LAYOUT, bool COUNT, bool TEX, int KIND>
-__global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
+template <int LAYOUT, bool COUNT, bool TEX, int KIND, bool BATCH = false, typename B = RtNoBatch>
+__global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p, const B bt) {
   constexpr bool PTSPLIT = KIND == KIND_PTSPLIT;
+  static_assert(!BATCH || KIND == KIND_PIXEL, "a batch runs the compute.wgsl pixel kind only");
   extern __shared__ __align__(16) unsigned char smem[];
 #ifdef RT_TIMELINE
   const unsigned long long tl_start = wall_clock64();
@@ -986,18 +1018,40 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
   Shade sh; sh.mode = p.mode; sh.gi_samples = p.gi_samples; sh.gi_bounces = p.gi_bounces; sh.soft_samples = p.soft_samples;
 
   const int lane = threadIdx.x & 63;
-  const float time_h = (float)hash_u32(sat_u32(p.U[38]));          // compute.wgsl:444
+  float time_h = (float)hash_u32(sat_u32(p.U[38]));          // compute.wgsl:444 (a batch: per frame, below)
   Work W; W.box = W.tri = W.hit = W.drops = 0;
   RayCount R; R.primary = R.shadow = R.bounce = 0;
   uint32_t pixels = 0;
-  const uint32_t n_list = *p.list_count;                 // written by k_compact (previous launch on this stream)
   uint32_t class_thr[N_CLASS];                           // class_thr[c], c >= 2: steps from which a pixel is of class c (k_compact)
 #pragma unroll
   for (int c = 2; c < N_CLASS; ++c) class_thr[c] = p.pix_class ? p.list_count[c] : 0xFFFFFFFFu;
   __shared__ uint32_t s_hist[64];                        // this block's step histogram of non-cheap pixels (next frame's threshold)
   if (threadIdx.x < 64) s_hist[threadIdx.x] = 0u;
   __syncthreads();
-  const uint32_t n_chunks = (n_list + 63u) / 64u;
+  // The chunk space.  One frame: the list's 64-pixel chunks, front to back.  A batch: the runs (class, frame) of all the
+  // frames' lists, hottest class of EVERY frame first (class-major, frame-minor), each run cut into its own chunks; lane o
+  // holds run o's first chunk, and a chunk id finds its run with one ballot.
+  uint32_t n_list = 0, n_chunks = 0;
+  uint32_t seg_first = 0xFFFFFFFFu, seg_start = 0, seg_count = 0, seg_frame = 0;   // BATCH: my run (lane = class rank * n + frame)
+  if constexpr (!BATCH) {
+    n_list = *p.list_count;                              // written by k_compact (previous launch on this stream)
+    n_chunks = (n_list + 63u) / 64u;
+  } else {
+    const uint32_t n_seg = bt.n * (uint32_t)N_CLASS;
+    uint32_t my_chunks = 0;
+    if ((uint32_t)lane < n_seg) {
+      seg_frame = (uint32_t)lane % bt.n;
+      const uint32_t c = (uint32_t)(N_CLASS - 1) - (uint32_t)lane / bt.n;              // hottest class first, cheap / unknown (0) last
+      const uint32_t* lc = p.list_count + (size_t)seg_frame * bt.lc_stride;
+      seg_start = lc[8 + c]; seg_count = lc[16 + c];
+      my_chunks = (seg_count + 63u) / 64u;
+    }
+    uint32_t inc = my_chunks;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, o); if (lane >= o) inc += t; }
+    n_chunks = (uint32_t)__shfl((int)inc, 63);
+    seg_first = ((uint32_t)lane < n_seg && my_chunks > 0u) ? inc - my_chunks : 0xFFFFFFFFu;   // empty runs never match
+  }
   const uint32_t per_xcd = (gridDim.x + 7u) / 8u;
   int shard = (int)((blockIdx.x & 7u) * (N_SHARD / 8) + ((blockIdx.x >> 3) * (N_SHARD / 8)) / per_xcd) & (N_SHARD - 1);
   for (uint32_t scans = 0; scans <= 4u * N_SHARD; ++scans) {          // every wave reaches the exit: a scan that finds nothing
@@ -1016,22 +1070,35 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
 #ifdef RT_TIMELINE
       tl_last = wall_clock64(); tl_chunks += 1;
 #endif
-      const uint32_t li = chunk * 64u + (uint32_t)lane;
+      // this chunk's frame and its entries of that frame's list
+      FrameView fv = frame_view<false>(p, bt, 0u);
+      uint32_t li, li_end;
+      bool last_frame = true;
+      if constexpr (!BATCH) { li = chunk * 64u + (uint32_t)lane; li_end = n_list; }
+      else {
+        const int o = 63 - __clzll((long long)__ballot(seg_first <= chunk));          // the last run that starts at or before this chunk (empty runs never match)
+        const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)seg_frame, o));
+        const uint32_t first = (uint32_t)__shfl((int)seg_first, o), start = (uint32_t)__shfl((int)seg_start, o), cnt = (uint32_t)__shfl((int)seg_count, o);
+        fv = frame_view<true>(p, bt, f);
+        li = start + (chunk - first) * 64u + (uint32_t)lane; li_end = start + cnt;
+        time_h = (float)hash_u32(sat_u32(fv.U[38]));
+        last_frame = f + 1u == bt.n;
+      }
       PtRec rec;
       bool rec_hit = false;
-      if (li < n_list) {
-        const uint32_t idx = p.list[li];
+      if (li < li_end) {
+        const uint32_t idx = fv.list[li];
         const uint32_t x = idx % p.width, lrow = idx / p.width;
         const uint32_t y = local_to_global_row(p, lrow);
         PixelOut o;
-        if constexpr (PTSPLIT) { o = shade_pt_primary<LAYOUT, COUNT, TEX>(S, sh, p.U, x, y, p.width, p.height, time_h, W, R, rec, rec_hit); rec.idx = idx; }
-        else if constexpr (KIND == KIND_FRAG_WEB) o = shade_frag<COUNT, 1>(S, sh, p.U, x, y, p.width, p.height, p.miss_rgba, W, R);
-        else if constexpr (KIND == KIND_FRAG_ROOT) o = shade_frag<COUNT, 2>(S, sh, p.U, x, y, p.width, p.height, p.miss_rgba, W, R);
-        else o = shade_pixel<LAYOUT, COUNT, TEX>(S, sh, p.U, x, y, p.width, p.height, time_h, W, R);
-        if (p.rgba8 && !rec_hit) reinterpret_cast<uint32_t*>(p.rgba8)[idx] = o.rgba;     // a PT hit pixel gets its colour in part 2
-        if (p.hit_tri) p.hit_tri[idx] = o.tri;
-        if (p.hit_t) p.hit_t[idx] = o.t;
-        if (p.pix_class) {
+        if constexpr (PTSPLIT) { o = shade_pt_primary<LAYOUT, COUNT, TEX>(S, sh, fv.U, x, y, p.width, p.height, time_h, W, R, rec, rec_hit); rec.idx = idx; }
+        else if constexpr (KIND == KIND_FRAG_WEB) o = shade_frag<COUNT, 1>(S, sh, fv.U, x, y, p.width, p.height, p.miss_rgba, W, R);
+        else if constexpr (KIND == KIND_FRAG_ROOT) o = shade_frag<COUNT, 2>(S, sh, fv.U, x, y, p.width, p.height, p.miss_rgba, W, R);
+        else o = shade_pixel<LAYOUT, COUNT, TEX>(S, sh, fv.U, x, y, p.width, p.height, time_h, W, R);
+        if (fv.rgba8 && !rec_hit) reinterpret_cast<uint32_t*>(fv.rgba8)[idx] = o.rgba;     // a PT hit pixel gets its colour in part 2
+        if (fv.hit_tri) fv.hit_tri[idx] = o.tri;
+        if (fv.hit_t) fv.hit_t[idx] = o.t;
+        if (p.pix_class && last_frame) {                  // a batch leaves the hints of its last frame
           uint32_t cls = o.cost >= p.class_t1 ? 1u : 0u;
 #pragma unroll
           for (int c = 2; c < N_CLASS; ++c) cls += o.cost >= class_thr[c] ? 1u : 0u;
@@ -1063,7 +1130,7 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p) {
     t[0] = tl_start; t[1] = tl_last; t[2] = wall_clock64(); t[3] = tl_chunks;
   }
 #endif
-  flush_stats<COUNT>(p, lane, R, W, pixels);
+  if constexpr (!BATCH) flush_stats<COUNT>(p, lane, R, W, pixels);     // a batch keeps no statistics
   if (p.pix_class) {                                     // 64 bins, one atomic per non-empty bin and block, spread over the launch's tail
     __syncthreads();
     if (threadIdx.x < 64 && s_hist[threadIdx.x]) atomicAdd(&p.class_hist[threadIdx.x], s_hist[threadIdx.x]);
@@ -1194,21 +1261,47 @@ __global__ __launch_bounds__(TBLK) void k_deinterleave(const T* __restrict__ pac
 // late behind another one (measured: with a 4-blocks/CU grid and 3 resident, a quarter of the
 // waves started 400 us into a 650 us launch).
 uint32_t rt_render_grid(int n_cu) { return (uint32_t)n_cu * 8u; }   // upper bound (sizes the per-block stats slots: two launches with the PT split)
-static uint32_t resident_grid(int n_cu, int max_stack, bool tex, int frag = 0) {
-  static int per_cu[4][33] = {};
-  int& slot = per_cu[frag ? 1 + frag : (tex ? 1 : 0)][max_stack];
-  if (slot == 0) {
+// The k_render instantiation a frame runs.  Every launch and every occupancy query goes through this one table, so the
+// persistent grid is sized from the kernel that is actually launched (COUNT = false variants hold fewer registers).
+template <int L, bool C, bool X, int K, bool BT>
+static const void* render_kernel_ptr() {
+  if constexpr (BT) return reinterpret_cast<const void*>(&k_render<L, C, X, K, true, RtBatch>);
+  else return reinterpret_cast<const void*>(&k_render<L, C, X, K, false, RtNoBatch>);
+}
+template <int K, bool BT>
+static const void* render_kernel_lcx(int layout, bool count, bool tex) {
+  if (layout == RT_LAYOUT_WIDE64) {
+    if (count) return tex ? render_kernel_ptr<RT_LAYOUT_WIDE64, true, true, K, BT>() : render_kernel_ptr<RT_LAYOUT_WIDE64, true, false, K, BT>();
+    return tex ? render_kernel_ptr<RT_LAYOUT_WIDE64, false, true, K, BT>() : render_kernel_ptr<RT_LAYOUT_WIDE64, false, false, K, BT>();
+  }
+  if (count) return tex ? render_kernel_ptr<RT_LAYOUT_AOS32, true, true, K, BT>() : render_kernel_ptr<RT_LAYOUT_AOS32, true, false, K, BT>();
+  return tex ? render_kernel_ptr<RT_LAYOUT_AOS32, false, true, K, BT>() : render_kernel_ptr<RT_LAYOUT_AOS32, false, false, K, BT>();
+}
+// frag kinds: WIDE64 records, constant albedo (rt_render_device rejects anything else); a batch: the pixel kind only
+static const void* render_kernel(int layout, bool count, bool tex, int kind, bool batch) {
+  if (kind == KIND_FRAG_WEB) return count ? render_kernel_ptr<RT_LAYOUT_WIDE64, true, false, KIND_FRAG_WEB, false>() : render_kernel_ptr<RT_LAYOUT_WIDE64, false, false, KIND_FRAG_WEB, false>();
+  if (kind == KIND_FRAG_ROOT) return count ? render_kernel_ptr<RT_LAYOUT_WIDE64, true, false, KIND_FRAG_ROOT, false>() : render_kernel_ptr<RT_LAYOUT_WIDE64, false, false, KIND_FRAG_ROOT, false>();
+  if (kind == KIND_PTSPLIT) return render_kernel_lcx<KIND_PTSPLIT, false>(layout, count, tex);
+  return batch ? render_kernel_lcx<KIND_PIXEL, true>(layout, count, tex) : render_kernel_lcx<KIND_PIXEL, false>(layout, count, tex);
+}
+static uint32_t resident_grid(int n_cu, int max_stack, const void* kernel) {
+  struct Slot { const void* k; int stack; int per_cu; };
+  static Slot slots[64];
+  static int n_slots = 0;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  int per_cu = 0;
+  for (int i = 0; i < n_slots; ++i) if (slots[i].k == kernel && slots[i].stack == max_stack) per_cu = slots[i].per_cu;
+  if (per_cu == 0) {
     int nb = 0;
     const size_t lds = (size_t)max_stack * TBLK * 8;
-    const hipError_t e = frag == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_render<RT_LAYOUT_WIDE64, true, false, KIND_FRAG_WEB>), TBLK, lds)
-                       : frag == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_render<RT_LAYOUT_WIDE64, true, false, KIND_FRAG_ROOT>), TBLK, lds)
-                       : tex ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_render<RT_LAYOUT_WIDE64, true, true, KIND_PIXEL>), TBLK, lds)
-                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (k_render<RT_LAYOUT_WIDE64, true, false, KIND_PIXEL>), TBLK, lds);
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, TBLK, lds);
     if (e != hipSuccess || nb < 1) nb = 2;
-    slot = nb > 4 ? 4 : nb;
-    if (const char* e = getenv("RTCORE_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= slot) slot = v; }
+    per_cu = nb > 4 ? 4 : nb;
+    if (const char* e = getenv("RTCORE_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= per_cu) per_cu = v; }
+    if (n_slots < 64) slots[n_slots++] = Slot{kernel, max_stack, per_cu};
   }
-  return (uint32_t)n_cu * (uint32_t)slot;
+  return (uint32_t)n_cu * (uint32_t)per_cu;
 }
 uint32_t rt_cull_blocks(uint32_t n_tiles) { return (n_tiles + CULL_TPB - 1) / CULL_TPB; }
 uint32_t rt_n_class() { return (uint32_t)N_CLASS; }
@@ -1273,46 +1366,57 @@ void rt_launch_render(const RtRenderParams& p_in, int layout, bool count_work, b
                       hipEvent_t ev1) {
   RtRenderParams p = p_in;
   const dim3 b(TBLK), gc(rt_cull_blocks(p.n_tiles));
-  p.render_blocks = resident_grid(n_cu, p.max_stack, p.tri_uv != nullptr, p.frag);
+  const bool tex = p.tri_uv != nullptr, split = p.pt_cap != 0;
+  const int kind = p.frag == 1 ? KIND_FRAG_WEB : p.frag == 2 ? KIND_FRAG_ROOT : split ? KIND_PTSPLIT : KIND_PIXEL;
+  if (p.frag) layout = RT_LAYOUT_WIDE64;
+  const void* kernel = render_kernel(layout, count_work, tex && !p.frag, kind, false);
+  p.render_blocks = resident_grid(n_cu, p.max_stack, kernel);
   // A persistent grid that fills the chip leaves a frame queued behind it nothing but its tail to overlap with.  Frames
   // in flight therefore take 2 of the (usually 3) resident blocks per CU each, so that two of them really run side by
   // side (cfg 3, two in flight: 0.440 -> 0.400 ms per frame; a 1/8 stripe share, three in flight: 0.146 -> 0.125 ms).
   if (p.blocks_per_cu_cap && !getenv("RTCORE_BLOCKS_PER_CU")) p.render_blocks = std::min(p.render_blocks, (uint32_t)n_cu * p.blocks_per_cu_cap);
-  hipLaunchKernelGGL(k_cull, gc, b, 0, s, p);
-  hipLaunchKernelGGL(k_compact, gc, b, 0, s, p);
+  RtNoBatch nb;
+  hipLaunchKernelGGL((k_cull<false, RtNoBatch>), gc, b, 0, s, p, nb);
+  hipLaunchKernelGGL((k_compact<false, RtNoBatch>), gc, b, 0, s, p, nb);
   const dim3 g(p.render_blocks);
   const size_t lds = (size_t)p.max_stack * TBLK * (sizeof(uint32_t) + sizeof(float));
   if (ev0) (void)hipEventRecord(ev0, s);
-  const bool tex = p.tri_uv != nullptr, split = p.pt_cap != 0;
-  // PT split: part 1 (k_render<..., true>) then part 2 (k_pt_samples) with its own rows of the per-block stats partials
-  RtRenderParams p2 = p;
-  p2.stats_partial = p.stats_partial + (size_t)g.x * 8;
-#define RT_LAUNCH_RENDER(L, C, X)                                                              \
-  do {                                                                                          \
-    if (split) {                                                                                \
-      hipLaunchKernelGGL((k_render<L, C, X, KIND_PTSPLIT>), g, b, lds, s, p);                   \
-      hipLaunchKernelGGL((k_pt_samples<L, C, X>), g, b, lds, s, p2);                            \
-      hipLaunchKernelGGL(k_pt_resolve, dim3((p.pt_cap + TBLK - 1) / TBLK, N_SHARD), b, 0, s, p); \
-    } else hipLaunchKernelGGL((k_render<L, C, X, KIND_PIXEL>), g, b, lds, s, p);                \
-  } while (0)
-  if (p.frag) {   // older fragment shaders: WIDE64 records, constant albedo (rt_render_device rejects anything else)
-    if (p.frag == 1) {
-      if (count_work) hipLaunchKernelGGL((k_render<RT_LAYOUT_WIDE64, true, false, KIND_FRAG_WEB>), g, b, lds, s, p);
-      else hipLaunchKernelGGL((k_render<RT_LAYOUT_WIDE64, false, false, KIND_FRAG_WEB>), g, b, lds, s, p);
+  void* args[2] = {&p, &nb};
+  (void)hipLaunchKernel(kernel, g, b, args, lds, s);
+  if (split) {   // PT split: part 1 (KIND_PTSPLIT) then part 2 (k_pt_samples) with its own rows of the per-block stats partials
+    RtRenderParams p2 = p;
+    p2.stats_partial = p.stats_partial + (size_t)g.x * 8;
+#define RT_LAUNCH_PT2(L, C, X) hipLaunchKernelGGL((k_pt_samples<L, C, X>), g, b, lds, s, p2)
+    if (layout == RT_LAYOUT_WIDE64) {
+      if (count_work) { if (tex) RT_LAUNCH_PT2(RT_LAYOUT_WIDE64, true, true); else RT_LAUNCH_PT2(RT_LAYOUT_WIDE64, true, false); }
+      else { if (tex) RT_LAUNCH_PT2(RT_LAYOUT_WIDE64, false, true); else RT_LAUNCH_PT2(RT_LAYOUT_WIDE64, false, false); }
     } else {
-      if (count_work) hipLaunchKernelGGL((k_render<RT_LAYOUT_WIDE64, true, false, KIND_FRAG_ROOT>), g, b, lds, s, p);
-      else hipLaunchKernelGGL((k_render<RT_LAYOUT_WIDE64, false, false, KIND_FRAG_ROOT>), g, b, lds, s, p);
+      if (count_work) { if (tex) RT_LAUNCH_PT2(RT_LAYOUT_AOS32, true, true); else RT_LAUNCH_PT2(RT_LAYOUT_AOS32, true, false); }
+      else { if (tex) RT_LAUNCH_PT2(RT_LAYOUT_AOS32, false, true); else RT_LAUNCH_PT2(RT_LAYOUT_AOS32, false, false); }
     }
-  } else if (layout == RT_LAYOUT_WIDE64) {
-    if (count_work) { if (tex) RT_LAUNCH_RENDER(RT_LAYOUT_WIDE64, true, true); else RT_LAUNCH_RENDER(RT_LAYOUT_WIDE64, true, false); }
-    else { if (tex) RT_LAUNCH_RENDER(RT_LAYOUT_WIDE64, false, true); else RT_LAUNCH_RENDER(RT_LAYOUT_WIDE64, false, false); }
-  } else {
-    if (count_work) { if (tex) RT_LAUNCH_RENDER(RT_LAYOUT_AOS32, true, true); else RT_LAUNCH_RENDER(RT_LAYOUT_AOS32, true, false); }
-    else { if (tex) RT_LAUNCH_RENDER(RT_LAYOUT_AOS32, false, true); else RT_LAUNCH_RENDER(RT_LAYOUT_AOS32, false, false); }
+#undef RT_LAUNCH_PT2
+    hipLaunchKernelGGL(k_pt_resolve, dim3((p.pt_cap + TBLK - 1) / TBLK, N_SHARD), b, 0, s, p);
   }
-#undef RT_LAUNCH_RENDER
   if (ev1) (void)hipEventRecord(ev1, s);
   if (want_stats) hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(256), 0, s, p, split ? 2u * g.x : g.x, p.local_rows * p.width, count_work ? 1 : 0);
+}
+
+// A batch: the frames' cull + compact passes as the y dimension of two launches, then ONE persistent k_render over all
+// the frames' lists (rt_render_batch_device).  p carries what the frames share (tree, geometry of the image, scratch
+// bases); bt what differs.  No stats, no PT split.
+void rt_launch_render_batch(const RtRenderParams& p_in, const RtBatch& bt, int layout, int n_cu, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+  RtRenderParams p = p_in;
+  RtBatch batch = bt;
+  const dim3 b(TBLK), gc(rt_cull_blocks(p.n_tiles), bt.n);
+  const void* kernel = render_kernel(layout, false, p.tri_uv != nullptr, KIND_PIXEL, true);
+  p.render_blocks = resident_grid(n_cu, p.max_stack, kernel);
+  hipLaunchKernelGGL((k_cull<true, RtBatch>), gc, b, 0, s, p, batch);
+  hipLaunchKernelGGL((k_compact<true, RtBatch>), gc, b, 0, s, p, batch);
+  const size_t lds = (size_t)p.max_stack * TBLK * (sizeof(uint32_t) + sizeof(float));
+  if (ev0) (void)hipEventRecord(ev0, s);
+  void* args[2] = {&p, &batch};
+  (void)hipLaunchKernel(kernel, dim3(p.render_blocks), b, args, lds, s);
+  if (ev1) (void)hipEventRecord(ev1, s);
 }
 
 void rt_launch_gather_uv(const float* texcoords, const uint32_t* tex_idx, const int32_t* material_ids, const uint32_t* order,
