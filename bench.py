@@ -65,6 +65,11 @@ def main():
                     help="asynchronous frames in flight per GPU (rtcore.h rt_set_frames_in_flight). auto = 1 on one GPU, so that every "
                          "k_render launch runs alone and its duration is the kernel's own (roofline), 3 with N > 1, where a rank's "
                          "share of the frame is small and mostly tail (3 frame streams + the context stream = the 4 hardware queues)")
+    ap.add_argument("--batch", default="auto", choices=["auto", "1", "2", "3", "4", "5", "6", "7", "8"],
+                    help="frames per pipeline (rtcore.h rt_render_batch_device). auto = 8 (RT_MAX_BATCH): the K steps run as ceil(K / 8) "
+                         "pipelines, each ONE k_render launch over the pixel lists of up to 8 frames (a frame, and even more a rank's "
+                         "stripe share of one, is mostly launch overhead + idle tail on its own: tools/batch_gain.py); with N > 1 one "
+                         "exchange per batch on a side stream.  1 = one frame per pipeline (the `per_frame` leg at N = 1)")
     ap.add_argument("--exchange", default="root", choices=["root", "all"],
                     help="N > 1: where the frame's stripes are gathered — root = rank 0 only (the viewer's rank: grouped send/recv, each "
                          "byte crosses one xGMI link once), all = every rank (all_gather, N times the traffic)")
@@ -145,7 +150,20 @@ def main():
     shade = dict(gi_samples=shade.gi_samples, gi_bounces=shade.gi_bounces, soft_samples=shade.soft_samples, max_stack=shade.max_stack)
     base = rt.render_opts(mode=mode, layout=layout, flags=tflag, **shade)
     fif = (1 if world == 1 else 3) if args.frames_in_flight == "auto" else int(args.frames_in_flight)
+    batch = 8 if args.batch == "auto" else int(args.batch)
+    if batch > 1:
+        fif = 1                         # a batch is its own overlap: it runs on the context stream
     frame = rdist.ShardedFrame(rdist.GpuBackend(ctx, device, frames_in_flight=fif), W, H, rank, world, base, exchange=args.exchange)
+    bframes = rdist.BatchedFrames(frame.b, W, H, rank, world, batch, base, exchange=args.exchange) if batch > 1 else None
+
+    def run_frames(views, n):
+        """n steps (frames) of the frame loop, views[i % len(views)] each: one frame per pipeline, or `batch` frames per pipeline."""
+        if bframes is None:
+            for i in range(n):
+                frame.step(views[i % len(views)], want_stats=False)
+            return
+        for i0 in range(0, n, batch):
+            bframes.step(np.stack([views[i % len(views)] for i in range(i0, min(i0 + batch, n))]))
 
     # one counted launch (untimed): rays + work counters of this rank's share of the frame
     copts = rt.render_opts(mode=mode, layout=layout, flags=rt.FLAG_COUNT_WORK | tflag, **shade,
@@ -163,11 +181,15 @@ def main():
 
     my_rays, my_rays_traced, my_frame_bytes, my_bytes = counted(U)
 
-    for _ in range(args.warmup):
-        frame.step(U, want_stats=False)
+    if bframes is not None:             # set-up, like the counted launch above: the first full batch sizes the pipeline's scratch
+        bframes.step(np.stack([U] * batch))
+        bframes.finish()
+    run_frames([U], args.warmup)
 
     def fence():
         frame.finish()
+        if bframes is not None:
+            bframes.finish()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -178,11 +200,11 @@ def main():
     # frames are queued asynchronously, as a frame loop would; hipEvents recorded on the context's own stream
     # around every frame's kernels (rt_profile_begin/end) give the per-kernel durations of exactly these K steps
     ctx.profile_begin()
-    for _ in range(args.steps):
-        frame.step(U, want_stats=False)
+    run_frames([U], args.steps)
     fence()
     elapsed = time.perf_counter() - t0
-    kernel_ms, trav_ms, _n = ctx.profile_end()   # frame pipeline (cull, compact, traversal, stats) / k_render alone
+    kernel_ms, trav_ms, n_launch = ctx.profile_end()   # frame pipeline (cull, compact, traversal, stats) / k_render alone, per launch
+    frames_per_launch = args.steps / max(n_launch, 1)  # 1, or the mean batch size (a k_render launch then walks that many frames' lists)
 
     # the same K frames again with two frames in flight (only where the main loop ran with one): whole-job throughput when
     # the tail of one frame may overlap the head of the next; reported beside `value`, never as `value` at N = 1
@@ -207,23 +229,26 @@ def main():
     # dragging the reference's rotY slider), where last frame's per-pixel hints are a few pixels off.
     legs = {}
     if world == 1 and not args.no_legs:
-        def leg(uniforms_list, rays_list, bytes_list):
-            for i in range(args.warmup):
-                frame.step(uniforms_list[i % len(uniforms_list)], want_stats=False)
+        def leg(uniforms_list, rays_list, bytes_list, per_frame=False):
+            go = (lambda n: [frame.step(uniforms_list[i % len(uniforms_list)], want_stats=False) for i in range(n)]) if per_frame \
+                else (lambda n: run_frames(uniforms_list, n))
+            go(max(args.warmup, batch))
             fence()
             t1 = time.perf_counter()
             ctx.profile_begin()
-            for i in range(args.steps):
-                frame.step(uniforms_list[i % len(uniforms_list)], want_stats=False)
+            go(args.steps)
             fence()
             e = time.perf_counter() - t1
-            _, tr_ms, _ = ctx.profile_end()
+            _, tr_ms, launches = ctx.profile_end()
             n = args.steps
             rays = sum(rays_list[i % len(rays_list)] for i in range(n))
             byts = sum(bytes_list[i % len(bytes_list)] for i in range(n))
-            ach = byts / n / (tr_ms * 1e-3) / 1e9 if tr_ms > 0 else 0.0
+            ach = byts / (tr_ms * launches * 1e-3) / 1e9 if tr_ms > 0 else 0.0      # all launches' bytes / all launches' time
             return {"value": round(rays / e / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(e / n * 1e3, 4),
-                    "kernel_ms": round(tr_ms, 4), "roofline_frac": round(ach / HBM_PEAK_GBS, 5)}
+                    "kernel_ms": round(tr_ms, 4), "frames_per_launch": round(n / max(launches, 1), 3), "roofline_frac": round(ach / HBM_PEAK_GBS, 5)}
+        if batch > 1:
+            legs["per_frame"] = leg([U], [my_rays], [my_bytes], per_frame=True)
+            legs["per_frame"]["what"] = "same static view, ONE frame per pipeline (rt_render_device, one frame in flight): the latency-bound loop of an interactive viewer"
         ctx.set_coherent_scheduling(False)
         legs["unhinted"] = leg([U], [my_rays], [my_bytes])
         legs["unhinted"]["what"] = "same static view, frame-coherent scheduling hints off (a first frame / camera cut runs at this speed)"
@@ -232,8 +257,7 @@ def main():
         cnt = [counted(v) for v in views]
         legs["moving_camera"] = leg(views, [c[0] for c in cnt], [c[3] for c in cnt])
         legs["moving_camera"]["what"] = "rotY + 1 degree per frame, hints on (tile-level promotion under motion)"
-        for _ in range(3):              # leave the context as the main loop had it: hints of the static view
-            frame.step(U, want_stats=False)
+        run_frames([U], 3 * batch)      # leave the context as the main loop had it: hints of the static view
         fence()
 
     tot = torch.tensor([float(my_rays), float(my_bytes), elapsed, kernel_ms, float(my_rays_traced)], dtype=torch.float64, device=device)
@@ -251,7 +275,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = total_rays * args.steps / elapsed / 1e6
         # roofline of the dominant kernel (traversal): this rank's algorithmic bytes / its average launch duration
-        achieved = my_bytes / (trav_ms * 1e-3) / 1e9 if trav_ms > 0 else 0.0
+        achieved = my_bytes * frames_per_launch / (trav_ms * 1e-3) / 1e9 if trav_ms > 0 else 0.0
         what = {"primary": "primary rays only", "shadow": "primary + 4 soft shadow rays",
                 "pt": f"full computeLighting_optimized: GI {args.spp} spp x 3 bounces + 4 soft shadow rays per vertex",
                 "frag-web": "web/shader.wgsl computeLighting_optimized: GI 32 x 3 bounces, 8-tap Poisson-disk light per vertex",
@@ -269,7 +293,7 @@ def main():
                                    f"layout {args.layout}, node records {'v2' if encoding == rt.NODES_V2 else 'v1'}, "
                                    + ("textured shading: 3 materials, map_Kd 2048^2 + 1024^2 closed-form RGB8, nearest texel" if textured
                                       else "constant albedo (compute.wgsl:372)"),
-                       "mode": args.mode, "rays_per_frame": int(total_rays), "rays_traced_per_frame": int(total_traced), "frames_in_flight": fif, "stripes": "16-row round-robin" if world > 1 else "none",
+                       "mode": args.mode, "rays_per_frame": int(total_rays), "rays_traced_per_frame": int(total_traced), "frames_in_flight": fif, "frames_per_pipeline": batch, "stripes": "16-row round-robin" if world > 1 else "none",
                        "exchange": ("gather to rank 0" if args.exchange == "root" else "all_gather") if world > 1 else "none"},
             "lbvh_build_ms": {k: round(float(v), 4) for k, v in build.items() if k.startswith("ms_")},
             "lbvh_build_roofline_frac": round(build["algorithmic_bytes"] / (build["ms_total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
@@ -281,7 +305,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc.get("k_render_hbm_bytes_per_launch"),
                          "traffic_source": pmc.get("source"),
-                         "kernel": "k_render", "kernel_ms": round(trav_ms, 4), "algorithmic_bytes_per_launch": int(my_bytes),
+                         "kernel": "k_render", "kernel_ms": round(trav_ms, 4), "algorithmic_bytes_per_launch": int(my_bytes * frames_per_launch),
+                         "frames_per_launch": round(frames_per_launch, 3),
                          "bytes_outside_kernel": int(my_frame_bytes - my_bytes),
                          # what actually binds the kernel: its working set is cache-resident, fabric traffic is a
                          # small share of the HBM roof, and the VALU lanes are half idle behind divergent 64-byte gathers

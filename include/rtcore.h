@@ -254,6 +254,10 @@ int rt_render_batch_device(rt_ctx* ctx, uint32_t n_frames, const float* uniforms
  * rows_per_rank x width x elem_bytes) into a full image; all pointers are device memory. */
 int rt_deinterleave_device(rt_ctx* ctx, const void* d_packed, void* d_image, uint32_t width, uint32_t height,
                            uint32_t elem_bytes, int32_t stripe_rows, int32_t stripe_world, uint32_t rows_per_rank);
+/* Same on a caller's hipStream_t of this GPU (NULL = rt_stream()): lets the exchange leg of frame i (collective +
+ * de-interleave) run beside the traversal of frame i+1, which owns the context stream. */
+int rt_deinterleave_device_on(rt_ctx* ctx, void* stream, const void* d_packed, void* d_image, uint32_t width, uint32_t height,
+                              uint32_t elem_bytes, int32_t stripe_rows, int32_t stripe_world, uint32_t rows_per_rank);
 
 /* ------------------------------------------------------------------ material / texture shading (extension) */
 /* The reference shades every surface with one constant albedo (compute.wgsl:372; no WGSL reads a vt, texture or

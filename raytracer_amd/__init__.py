@@ -312,9 +312,14 @@ class Context:
             return (C.c_void_p * n)(*[C.c_void_p(int(x) or None) for x in a])
         self._chk(_L.rt_render_batch_device(self._h, n, _vp(U), C.byref(opts), ptrs(d_rgba8), ptrs(d_hit_tri), ptrs(d_hit_t)))
 
-    def deinterleave_device(self, d_packed, d_image, width, height, elem_bytes, stripe_rows, world, rows_per_rank):
-        self._chk(_L.rt_deinterleave_device(self._h, C.c_void_p(d_packed), C.c_void_p(d_image), width, height, elem_bytes,
-                                            stripe_rows, world, rows_per_rank))
+    def deinterleave_device(self, d_packed, d_image, width, height, elem_bytes, stripe_rows, world, rows_per_rank, stream=None):
+        """stream: a hipStream_t (integer) of this GPU to launch on instead of the context stream."""
+        if stream is None:
+            self._chk(_L.rt_deinterleave_device(self._h, C.c_void_p(d_packed), C.c_void_p(d_image), width, height, elem_bytes,
+                                                stripe_rows, world, rows_per_rank))
+        else:
+            self._chk(_L.rt_deinterleave_device_on(self._h, C.c_void_p(stream or None), C.c_void_p(d_packed), C.c_void_p(d_image),
+                                                   width, height, elem_bytes, stripe_rows, world, rows_per_rank))
 
     # ---- multi-GPU plumbing
     def bvh_view(self):

@@ -25,7 +25,7 @@ SYMBOLS = [
     "rt_normalize_mesh", "rt_camera_default", "rt_make_uniforms",
     "rt_set_mesh", "rt_build_lbvh", "rt_get_bounds", "rt_get_morton", "rt_get_tri_order", "rt_get_counts",
     "rt_get_nodes", "rt_get_triangles", "rt_set_bvh", "rt_save_bvh", "rt_load_bvh",
-    "rt_render_opts_default", "rt_render_opts_for_mode", "rt_render", "rt_render_device", "rt_packed_rows", "rt_deinterleave_device",
+    "rt_render_opts_default", "rt_render_opts_for_mode", "rt_render", "rt_render_device", "rt_packed_rows", "rt_deinterleave_device", "rt_deinterleave_device_on",
     "rt_bvh_view_get", "rt_bvh_export_device", "rt_bvh_adopt_device", "rt_synchronize", "rt_stream",
     "rt_profile_begin", "rt_profile_end", "rt_set_node_encoding", "rt_get_node_encoding",
     "rt_set_surface", "rt_get_tri_uv", "rt_set_tri_uv", "rt_set_materials", "rt_set_texture", "rt_tri_uv_device",
@@ -146,6 +146,7 @@ def load():
         "rt_render_batch_device": (C.c_int, [vp, C.c_uint32, vp, C.POINTER(RenderOpts), vp, vp, vp]),
         "rt_packed_rows": (u32, [u32, i32, i32, i32]),
         "rt_deinterleave_device": (C.c_int, [vp, vp, vp, u32, u32, u32, i32, i32, u32]),
+        "rt_deinterleave_device_on": (C.c_int, [vp, vp, vp, vp, u32, u32, u32, i32, i32, u32]),
         "rt_bvh_view_get": (C.c_int, [vp, C.POINTER(BvhView)]),
         "rt_bvh_export_device": (C.c_int, [vp, C.POINTER(BvhView)]),
         "rt_bvh_adopt_device": (C.c_int, [vp, C.POINTER(BvhView)]),

@@ -1136,8 +1136,14 @@ int render_batch(rt_ctx* ctx, uint32_t n_frames, const float* uniforms, const rt
     bool moved = std::memcmp(ctx->last_uniforms, uniforms, sizeof(float) * 44) != 0;
     for (uint32_t f = 1; f < n_frames; ++f) moved = moved || std::memcmp(uniforms, uniforms + 44 * (size_t)f, sizeof(float) * 44) != 0;
     std::memcpy(ctx->last_uniforms, uniforms + 44 * (size_t)(n_frames - 1), sizeof(float) * 44);
-    rc = setup_hints(ctx, p, opts, moved, slot, s);
-    if (rc != RT_OK) return rc;
+    // Hints order a batch only while the view stands still.  Under motion the newest hints are up to a batch old (8
+    // frames at 1 degree each) and the batch's own length already hides the tail they are for: tools/batch_gain.py,
+    // 8 frames, turning 1 degree per frame, k_render roofline fraction with / without hints: cfg 3 0.883 / 0.932, S70k 1080p
+    // 0.717 / 0.764, a 1/8 stripe share 0.596 / 0.581; static view 0.964 / 0.948, 0.778 / 0.758, 0.701 / 0.604.
+    if (!moved) {
+      rc = setup_hints(ctx, p, opts, false, slot, s);
+      if (rc != RT_OK) return rc;
+    }
   }
   for (uint32_t f = 0; f < n_frames; ++f) {
     RtRenderParams pf = p;
@@ -1279,15 +1285,21 @@ extern "C" int rt_render(rt_ctx* ctx, const float uniforms[44], const rt_render_
   return RT_OK;
 }
 
-extern "C" int rt_deinterleave_device(rt_ctx* ctx, const void* d_packed, void* d_image, uint32_t width, uint32_t height,
-                                      uint32_t elem_bytes, int32_t stripe_rows, int32_t stripe_world, uint32_t rows_per_rank) {
+extern "C" int rt_deinterleave_device_on(rt_ctx* ctx, void* stream, const void* d_packed, void* d_image, uint32_t width, uint32_t height,
+                                         uint32_t elem_bytes, int32_t stripe_rows, int32_t stripe_world, uint32_t rows_per_rank) {
   if (!ctx) return RT_ERR_INVALID;
   if (!d_packed || !d_image || width == 0 || height == 0 || stripe_rows <= 0 || stripe_world < 1 || (elem_bytes != 1 && elem_bytes != 4))
     return ctx->fail(RT_ERR_INVALID, "rt_deinterleave_device: bad argument");
   const uint32_t need = rt_packed_rows(height, stripe_rows, 0, stripe_world);   // rank 0 always holds the most rows
   if (rows_per_rank < need) return ctx->fail(RT_ERR_INVALID, "rt_deinterleave_device: rows_per_rank too small");
   DeviceGuard g(ctx->device);
-  rt_launch_deinterleave(d_packed, d_image, width, height, elem_bytes, stripe_rows, stripe_world, rows_per_rank, ctx->stream);
+  rt_launch_deinterleave(d_packed, d_image, width, height, elem_bytes, stripe_rows, stripe_world, rows_per_rank,
+                         stream ? static_cast<hipStream_t>(stream) : ctx->stream);
   HIPCHK(hipGetLastError());
   return RT_OK;
+}
+
+extern "C" int rt_deinterleave_device(rt_ctx* ctx, const void* d_packed, void* d_image, uint32_t width, uint32_t height,
+                                      uint32_t elem_bytes, int32_t stripe_rows, int32_t stripe_world, uint32_t rows_per_rank) {
+  return rt_deinterleave_device_on(ctx, nullptr, d_packed, d_image, width, height, elem_bytes, stripe_rows, stripe_world, rows_per_rank);
 }

@@ -1,6 +1,6 @@
 """Multi-GPU host logic: one process per GPU, torch.distributed (RCCL) for
 the two exchange steps the path really has —
-  * BVH replication: built once on rank 0, the three flat buffers are broadcast over xGMI;
+  * BVH replication: built once on rank 0, the flat buffers travel as one blob, scatter + all-gather over xGMI;
   * framebuffer gather: each rank renders its 16-row stripes (stripe s -> rank s % world) into
     a PACKED buffer; the equal-sized packed buffers are gathered — to rank 0 only (exchange="root": the viewer's rank,
     grouped send/recv, every byte crosses one xGMI link once, 1/world of an all-gather's traffic) or to every rank
@@ -39,6 +39,7 @@ class GpuBackend:
         ctx.set_frames_in_flight(self.fif)     # the tail of frame i overlaps the head of frame i+1 (rtcore.h)
         # the context's own HIP stream, seen from torch: the collective and the de-interleave of a frame are queued on it
         self.ext = torch.cuda.ExternalStream(ctx.stream(), device=device)
+        self._side = None
 
     def alloc(self, rows, width):
         return torch.zeros((rows, width), dtype=torch.int32, device=self.device)
@@ -61,7 +62,47 @@ class GpuBackend:
 
     def finish(self):
         self.ctx.synchronize()
+        if self._side is not None:
+            self._side.synchronize()
         torch.cuda.current_stream(self.device).synchronize()
+
+    # ---- batches (BatchedFrames): B frames per pipeline, their exchange on a side stream
+    def render_packed_batch(self, Us, opts, packed):
+        """packed: [B, rows, width]; frame f of the batch goes to packed[f] (rt_render_batch_device, asynchronous)."""
+        self.ctx.render_batch_device(Us, opts, [packed[f].data_ptr() for f in range(len(Us))])
+
+    def side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
+    def mark(self):
+        """An event behind everything queued on the context stream so far."""
+        ev = torch.cuda.Event()
+        ev.record(self.ext)
+        return ev
+
+    def wait_for(self, ev):
+        """The context stream waits for `ev` (device-side; the host does not block)."""
+        if ev is not None:
+            self.ext.wait_event(ev)
+
+    def exchange_batch(self, gathered, packed, images, after, root_only, width, height, world, rpr):
+        """Gather of a whole batch ([B, rpr, width] per rank, ONE collective) and the de-interleave of its B frames, all on
+        the side stream behind event `after`: the context stream is free to traverse the next batch meanwhile.
+        -> the event that ends the exchange (the packed / gathered buffers may be reused behind it)."""
+        side = self.side_stream()
+        side.wait_event(after)
+        with torch.cuda.stream(side):
+            gather_stripes(gathered, packed, root_only)
+            if images is not None:
+                n = packed.shape[0]
+                for f in range(n):    # frame f of rank r sits at row (r * n + f) * rpr of `gathered`
+                    self.ctx.deinterleave_device(gathered.data_ptr() + 4 * f * rpr * width, images[f].data_ptr(), width, height, 4,
+                                                 STRIPE_ROWS, world, n * rpr, stream=side.cuda_stream)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return ev
 
 
 def gather_stripes(gathered, packed, root_only):
@@ -75,8 +116,11 @@ def gather_stripes(gathered, packed, root_only):
 
 
 def replicate_bvh(ctx, rank, world, device):
-    """Broadcast rank 0's flat BVH (nodes, triPos, triNor, and the BVH-order surface records when the scene has them)
-    and adopt it on every other rank.  Returns the tensors that back the adopted BVH (keep them alive).
+    """Rank 0's flat BVH (nodes, triPos, triNor, and the BVH-order surface records when the scene has them) to every rank:
+    ONE blob, scattered in `world` equal chunks (rank 0 sends 1/world of it down each of its links at once) and then
+    all-gathered (every link carries chunks in parallel) - instead of rooted broadcasts that push the whole blob (16 GB
+    for cfg 5) through rank 0's links once per buffer.  Every other rank adopts the blob's segments in place.
+    Returns the tensors that back the adopted BVH (keep them alive).
     Materials and textures are small host-side descriptions: every rank sets them itself."""
     meta = torch.zeros(4, dtype=torch.int64, device=device)
     if rank == 0:
@@ -85,26 +129,33 @@ def replicate_bvh(ctx, rank, world, device):
         meta[0], meta[1], meta[2], meta[3] = T, N, ctx.node_encoding(), 1 if uv_bytes else 0
     dist.broadcast(meta, 0)
     T, N, enc, has_uv = int(meta[0]), int(meta[1]), int(meta[2]), int(meta[3])
-    bufs = [torch.empty(32 * N, dtype=torch.uint8, device=device), torch.empty(48 * T, dtype=torch.uint8, device=device),
-            torch.empty(48 * T, dtype=torch.uint8, device=device)]
+    seg = [32 * N, 48 * T, 48 * T] + ([32 * T] if has_uv else [])      # bytes; every offset is a multiple of 16
+    off = [0]
+    for n in seg:
+        off.append(off[-1] + n)
+    align = 256 * world
+    total = (off[-1] + align - 1) // align * align
+    blob = torch.empty(total, dtype=torch.uint8, device=device)
+    base = blob.data_ptr()
     if rank == 0:
-        ctx.export_bvh_device(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), N, T)
-    for b in bufs:                      # three large broadcasts (32 B x N, 48 B x T, 48 B x T)
-        dist.broadcast(b, 0)
-    uv = None
-    if has_uv:                          # 32 B x T surface records
-        uv = torch.empty(32 * T, dtype=torch.uint8, device=device)
-        if rank == 0:
-            ctx.export_tri_uv_device(uv.data_ptr(), T)
-        dist.broadcast(uv, 0)
+        ctx.export_bvh_device(base + off[0], base + off[1], base + off[2], N, T)
+        if has_uv:
+            ctx.export_tri_uv_device(base + off[3], T)
+        if torch.device(device).type == "cuda":
+            ctx.synchronize()           # the exports ran on the context stream; the collectives below run on torch's
+    if world > 1:
+        chunk = torch.empty(total // world, dtype=torch.uint8, device=device)
+        dist.scatter(chunk, list(blob.view(world, -1).unbind(0)) if rank == 0 else None, src=0)
+        dist.all_gather_into_tensor(blob, chunk)        # (rank 0 receives what it already holds)
+        del chunk
     if torch.device(device).type == "cuda":
         torch.cuda.synchronize(device)
     if rank != 0:
         ctx.set_node_encoding(enc)          # v1 / v2 node records travel as the same 32-byte slots
-        ctx.adopt_bvh_device(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), N, T)
-        if uv is not None:
-            ctx.adopt_tri_uv_device(uv.data_ptr(), T)   # copied: `uv` need not be kept
-    return bufs
+        ctx.adopt_bvh_device(base + off[0], base + off[1], base + off[2], N, T)
+        if has_uv:
+            ctx.adopt_tri_uv_device(base + off[3], T)   # copied
+    return [blob] if rank != 0 else []      # rank 0 renders from its own build: its copy of the blob is dropped here
 
 
 class ShardedFrame:
@@ -176,5 +227,89 @@ class ShardedFrame:
     def finish(self):
         if self.collective:
             self.finish_exchange()
+        if hasattr(self.b, "finish"):
+            self.b.finish()
+
+
+class BatchedFrames:
+    """B frames of one image shape per step: this rank's stripes of all B frames are rendered by ONE pipeline
+    (rt_render_batch_device: the launches' fixed cost and the idle tail of a small stripe share are paid once per batch,
+    not once per frame), exchanged by ONE collective of [B, rows_per_rank, width] per rank and de-interleaved into B images.
+    Software-pipelined like ShardedFrame: step i queues the traversal of batch i on the context stream, then the exchange
+    of batch i-1 on a side stream, so xGMI transfer + de-interleave overlap the next batch's traversal; two packed /
+    gathered buffer sets alternate, and batch i+2 starts behind the exchange that read set i.
+    Backends without streams (the CPU oracle backend of the gloo tests) run the same steps synchronously."""
+
+    def __init__(self, backend, width, height, rank, world, batch, base_opts=None, force_collective=False, exchange="root"):
+        if exchange not in ("all", "root"):
+            raise ValueError("exchange must be 'all' or 'root'")
+        if not 1 <= batch <= 8:
+            raise ValueError("batch must be in [1, 8] (RT_MAX_BATCH)")
+        self.b, self.w, self.h, self.rank, self.world, self.batch = backend, width, height, rank, world, batch
+        self.root_only = exchange == "root"
+        self.has_frame = rank == 0 or not self.root_only
+        self.collective = world > 1 or force_collective
+        self.rpr = rows_per_rank(height, world) if world > 1 else height
+        o = base_opts or render_opts()
+        self.opts = render_opts(mode=o.mode, gi_samples=o.gi_samples, gi_bounces=o.gi_bounces, soft_samples=o.soft_samples,
+                                max_stack=o.max_stack, layout=o.layout, flags=o.flags,
+                                stripe_rows=STRIPE_ROWS if world > 1 else 0, stripe_rank=rank, stripe_world=world)
+        alloc3 = lambda n, rows: backend.alloc(n * rows, width).view(n, rows, width)
+        self.packed_ring = [alloc3(batch, self.rpr) for _ in range(2)]
+        self.gathered_ring = ([alloc3(world * batch, self.rpr) if self.has_frame else None for _ in range(2)] if self.collective else None)
+        self.images = (alloc3(batch, height) if self.has_frame else None) if self.collective else self.packed_ring[0]
+        self.rendered = [None, None]   # per buffer set: event behind the batch's traversal
+        self.free = [None, None]       # per buffer set: event behind the exchange that read it
+        self.count = [0, 0]            # per buffer set: frames of the batch it holds
+        self.prev = None
+        self.n_steps = 0
+        self.streams = hasattr(backend, "exchange_batch")
+
+    def step(self, Us):
+        """Us: [batch, 44] uniforms.  Asynchronous; finish() before reading self.images (the frames of the LAST batch)."""
+        Us = np.ascontiguousarray(Us, np.float32).reshape(-1, 44)
+        n = Us.shape[0]
+        if not 1 <= n <= self.batch:
+            raise ValueError(f"a step takes 1 .. {self.batch} frames")
+        slot = self.n_steps % 2
+        self.n_steps += 1
+        self.count[slot] = n             # a short batch (the tail of a frame loop) uses the front of the buffers
+        packed = self.packed_ring[slot][:n]
+        if self.streams:
+            self.b.wait_for(self.free[slot])
+        if hasattr(self.b, "render_packed_batch"):
+            self.b.render_packed_batch(Us, self.opts, packed)
+        else:
+            for f in range(n):
+                self.b.render_packed(Us[f], self.opts, packed[f], False)
+        if not self.collective:
+            self.images = packed
+            return
+        if self.streams:
+            self.rendered[slot] = self.b.mark()
+        if self.prev is not None:
+            self._exchange(self.prev)
+        self.prev = slot
+
+    def _exchange(self, slot):
+        n = self.count[slot]
+        packed, gathered = self.packed_ring[slot][:n], self.gathered_ring[slot]
+        if gathered is not None:
+            gathered = gathered.view(-1)[:self.world * n * self.rpr * self.w].view(self.world * n, self.rpr, self.w)
+        images = self.images[:n] if self.images is not None else None
+        if self.streams:
+            self.free[slot] = self.b.exchange_batch(gathered, packed, images, self.rendered[slot], self.root_only,
+                                                    self.w, self.h, self.world, self.rpr)
+            return
+        gather_stripes(gathered.view(-1, self.w) if gathered is not None else None, packed.reshape(-1, self.w), self.root_only)
+        if self.has_frame:
+            g = gathered.view(self.world, n, self.rpr, self.w)
+            for f in range(n):
+                self.b.deinterleave(g[:, f].contiguous().view(-1, self.w), images[f], self.w, self.h, self.world, self.rpr)
+
+    def finish(self):
+        if self.collective and self.prev is not None:
+            self._exchange(self.prev)
+            self.prev = None
         if hasattr(self.b, "finish"):
             self.b.finish()

@@ -96,7 +96,7 @@ def _worker(rank, world, port, q):
         keep = rdist.replicate_bvh(ctx, rank, world, "cpu")           # BVH built on rank 0 only, broadcast to the rest
         assert rank == 0 or np.array_equal(ctx.adopted_uv, uv_ref)
         mine = bvh if rank == 0 else ctx.adopted
-        assert mine is not None and len(keep) == 3
+        assert mine is not None and len(keep) == (0 if rank == 0 else 1)
         w, h = 50, 70                                                   # not multiples of the 16-row stripes
         U = rt.make_uniforms(w, h, cam_pos=(0.0, 0.0, 3.0))
         U[20:36] = np.eye(4, dtype=np.float32).reshape(-1)
@@ -129,6 +129,24 @@ def _worker(rank, world, port, q):
         rframe.finish()
         if rank == 0:
             ok = ok and np.array_equal(rframe.image.numpy(), refs[-1])
+        # batches: 2 frames per step through one exchange of [2, rows_per_rank, w] per rank (BatchedFrames); the frames of
+        # batch i are complete after step i+1 or finish()
+        for exchange in ("root", "all"):
+            bf = rdist.BatchedFrames(OracleBackend(oracle, mine), w, h, rank, world, 2, rt.render_opts(mode=rt.MODE_SHADOW), exchange=exchange)
+            has = rank == 0 or exchange == "all"
+            ok = ok and ((bf.images is None) == (not has))
+            Ub = []
+            for cam in cams:
+                Uk = rt.make_uniforms(w, h, cam_pos=cam)
+                Uk[20:36] = np.eye(4, dtype=np.float32).reshape(-1)
+                Ub.append(Uk)
+            bf.step(np.stack(Ub[0:2]))
+            bf.step(np.stack(Ub[2:4]))
+            if has:
+                ok = ok and np.array_equal(bf.images[0].numpy(), refs[0]) and np.array_equal(bf.images[1].numpy(), refs[1])
+            bf.finish()
+            if has:
+                ok = ok and np.array_equal(bf.images[0].numpy(), refs[2]) and np.array_equal(bf.images[1].numpy(), refs[3])
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

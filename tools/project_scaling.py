@@ -9,6 +9,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -26,6 +27,34 @@ dev = torch.device("cuda:0")
 W, H = 3840, 2160
 U = rt.make_uniforms(W, H, cam_pos=(0.0, 0.0, 1.3))
 base = rt.render_opts(mode=rt.MODE_SHADOW, flags=rt.FLAG_TEXTURED)
+
+
+def run_batched(world, rank, batch, n=200):
+    """The N > 1 loop of bench.py: `batch` frames per pipeline, one exchange per batch on a side stream."""
+    f = rdist.BatchedFrames(rdist.GpuBackend(ctx, dev, frames_in_flight=1), W, H, 0, 1, batch, base, force_collective=True)
+    rpr = rdist.rows_per_rank(H, world)
+    f.rpr = rpr
+    f.opts = rt.render_opts(mode=base.mode, flags=base.flags, stripe_rows=16, stripe_rank=rank, stripe_world=world)
+    alloc3 = lambda k, rows: f.b.alloc(k * rows, W).view(k, rows, W)
+    f.packed_ring = [alloc3(batch, rpr) for _ in range(2)]
+    f.gathered_ring = [alloc3(batch, rpr) for _ in range(2)]
+    f.images = alloc3(batch, rpr)
+    f.h = rpr                        # de-interleave of a 1-rank "image" of rpr rows
+    Ub = np.stack([U] * batch)
+    for _ in range(8):
+        f.step(Ub)
+    f.finish()
+    torch.cuda.synchronize()
+    chunks = []
+    nb = max(1, n // 4 // batch)
+    for _ in range(4):
+        t0 = time.perf_counter()
+        for _ in range(nb):
+            f.step(Ub)
+        f.finish()
+        torch.cuda.synchronize()
+        chunks.append((time.perf_counter() - t0) / (nb * batch) * 1e3)
+    return sorted(chunks)[1]
 
 
 def run(world, rank, fif, n=200):
@@ -65,8 +94,9 @@ order = (lambda w: range(w)) if "--reverse" not in sys.argv else (lambda w: reve
 t1 = run(1, 0, 1)
 print(f"N=1 (one frame in flight, as bench.py): {t1:.4f} ms/frame", flush=True)
 worlds = (2, 4, 8) if "--worlds" not in sys.argv else tuple(int(v) for v in sys.argv[sys.argv.index("--worlds") + 1].split(","))
+BATCH = int(os.environ.get("PROJ_BATCH", "4"))       # 1: one frame per pipeline with PROJ_FIF frames in flight (the round-1 loop)
 for world in worlds:
-    ts = {r: run(world, r, int(os.environ.get("PROJ_FIF", "3"))) for r in order(world)}
+    ts = {r: (run_batched(world, r, BATCH) if BATCH > 1 else run(world, r, int(os.environ.get("PROJ_FIF", "3")))) for r in order(world)}
     ts = [ts[r] for r in range(world)]
     print(f"N={world}: per-rank ms/frame {[round(t, 4) for t in ts]} -> slowest {max(ts):.4f}, projected speed-up {t1 / max(ts):.2f}x "
           f"({t1 / max(ts) / world * 100:.0f} % of linear)", flush=True)
