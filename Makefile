@@ -33,8 +33,8 @@ host: raytracer_amd/bin/rt_host
 
 raytracer_amd/bin/rt_host: src/main.cpp include/rtcore.h $(LIB)
 	@mkdir -p raytracer_amd/bin
-	g++ -std=c++17 -O2 -Wall -Wextra -Iinclude src/main.cpp -o $@ -Lraytracer_amd/lib -lrtcore \
-	    -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath-link,/opt/rocm/lib
+	g++ -std=c++17 -O2 -Wall -Wextra -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include src/main.cpp -o $@ -Lraytracer_amd/lib -lrtcore \
+	    -L/opt/rocm/lib -lrccl -lamdhip64 -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib
 
 clean:
 	rm -rf build raytracer_amd/lib/librtcore.so raytracer_amd/bin

@@ -57,3 +57,36 @@ def test_cpp_host_frame_matches_oracle(oracle, rt, plane_obj_path, tmp_path, tex
     ref, _ = oracle.render(b["nodes"], b["tri_pos"], b["tri_nor"], U, mode=1, n_threads=8, surface=surf)
     assert (ref["hit_tri"] != 0xFFFFFFFF).mean() > 0.02
     assert np.array_equal(img, ref["rgba8"][..., :3])
+
+
+@pytest.mark.parametrize("textured", [False, True])
+def test_cpp_host_rccl_world1_equals_single_process(plane_obj_path, tmp_path, textured):
+    """rt_host --gpus 1: the multi-GPU program (fork before any HIP call, RCCL communicator, BVH blob export -> scatter /
+    all-gather -> batched stripe render -> grouped send/recv gather -> de-interleave) with a world of one.  Its frame must
+    be the single-process frame byte for byte, for 1 frame, for a full batch and for a batch with a ragged tail."""
+    from raytracer_amd import scenes
+    assert os.path.exists(HOST)
+    d = tmp_path
+    shutil.copy(plane_obj_path, d / "plane.obj")
+    shutil.copy(os.path.join(ROOT, "tests", "golden", "plane_standin.mtl"), d / "plane_material.mtl")
+    _write_ppm(d / "standin_checker_0.rgb", scenes.procedural_texture(128, 0))
+    _write_ppm(d / "standin_checker_1.rgb", scenes.procedural_texture(32, 1))
+    w, h = 200, 120
+    base = [HOST, "--obj", str(d / "plane.obj"), "--width", str(w), "--height", str(h), "--mode", "shadow", "--cam", "0", "0", "0.6"] \
+        + (["--textured"] if textured else [])
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "raytracer_amd", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", ""),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run(base + ["--out", str(d / "single.ppm")], capture_output=True, text=True, timeout=120, env=env)
+    assert res.returncode == 0, res.stderr
+    single = json.loads(res.stdout.strip().splitlines()[-1])
+    ref = _read_ppm(d / "single.ppm")
+    assert ref.reshape(-1, 3).max(axis=0).max() > 0
+    for frames, batch in ((1, 8), (8, 4), (7, 3)):
+        out = d / f"multi_{frames}_{batch}.ppm"
+        res = subprocess.run(base + ["--gpus", "1", "--frames", str(frames), "--batch", str(batch), "--out", str(out)],
+                             capture_output=True, text=True, timeout=180, env=env)
+        assert res.returncode == 0, res.stderr[-2000:]
+        info = json.loads(res.stdout.strip().splitlines()[-1])
+        assert info["n_gpus"] == 1 and info["frames"] == frames and info["frames_per_pipeline"] == batch
+        assert info["triangles"] == single["triangles"] and info["nodes"] == single["nodes"] and info["rays"] == single["rays"]
+        assert np.array_equal(_read_ppm(out), ref), f"--gpus 1 --frames {frames} --batch {batch}"
