@@ -84,6 +84,11 @@ int  rt_mesh_parse_obj(const char* obj_text, size_t obj_len, const char* mtl_tex
                        rt_mesh** out, char* err, size_t err_len);
 int  rt_mesh_view_get(const rt_mesh* m, rt_mesh_view* out);
 int  rt_mesh_material(const rt_mesh* m, uint32_t i, rt_material* out);
+/* material_t::unknown_parameter (tiny_obj_loader.h:247, filled at :2749-2762): the `key value` lines of the MTL that
+ * tinyobj has no field for, in std::map order (sorted by key; the first value of a repeated key wins).  The strings
+ * live as long as the mesh. */
+uint32_t rt_mesh_material_n_unknown(const rt_mesh* m, uint32_t i);
+int  rt_mesh_material_unknown(const rt_mesh* m, uint32_t i, uint32_t k, const char** key, const char** value);
 void rt_mesh_free(rt_mesh* m);
 
 /* Replaces normalizeMesh, web/script.js:207-227 (in place; double math, f32 store). */

@@ -51,8 +51,14 @@ def _mesh_from_handle(h):
         for i in range(v.n_materials):
             m = _abi.Material()
             _L.rt_mesh_material(h, i, C.byref(m))
+            unknown = {}
+            for k in range(_L.rt_mesh_material_n_unknown(h, i)):
+                key, val = C.c_char_p(), C.c_char_p()
+                _L.rt_mesh_material_unknown(h, i, k, C.byref(key), C.byref(val))
+                unknown[key.value.decode()] = val.value.decode()
             mats.append(dict(name=m.name.decode(), diffuse=tuple(m.diffuse), emission=tuple(m.emission), dissolve=m.dissolve,
-                             illum=m.illum, map_Kd=m.diffuse_texname.decode(), map_Bump=m.bump_texname.decode()))
+                             illum=m.illum, map_Kd=m.diffuse_texname.decode(), map_Bump=m.bump_texname.decode(),
+                             unknown_parameter=unknown))
         return Mesh(arr(v.positions, 3 * v.n_vert, np.float32), arr(v.normals, 3 * v.n_nor, np.float32),
                     arr(v.vert_idx, 3 * v.n_tri, np.uint32), arr(v.nor_idx, 3 * v.n_tri, np.uint32),
                     arr(v.texcoords, 2 * v.n_tex, np.float32), arr(v.tex_idx, 3 * v.n_tri, np.uint32),

@@ -21,7 +21,7 @@ NODES_V1, NODES_V2 = 1, 2
 # every symbol include/rtcore.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_abi_version",
-    "rt_mesh_load_obj", "rt_mesh_parse_obj", "rt_mesh_view_get", "rt_mesh_material", "rt_mesh_free",
+    "rt_mesh_load_obj", "rt_mesh_parse_obj", "rt_mesh_view_get", "rt_mesh_material", "rt_mesh_material_n_unknown", "rt_mesh_material_unknown", "rt_mesh_free",
     "rt_normalize_mesh", "rt_camera_default", "rt_make_uniforms",
     "rt_set_mesh", "rt_build_lbvh", "rt_get_bounds", "rt_get_morton", "rt_get_tri_order", "rt_get_counts",
     "rt_get_nodes", "rt_get_triangles", "rt_set_bvh", "rt_save_bvh", "rt_load_bvh",
@@ -123,6 +123,8 @@ def load():
         "rt_mesh_parse_obj": (C.c_int, [cp, C.c_size_t, cp, C.c_size_t, C.POINTER(vp), C.c_char_p, C.c_size_t]),
         "rt_mesh_view_get": (C.c_int, [vp, C.POINTER(MeshView)]),
         "rt_mesh_material": (C.c_int, [vp, u32, C.POINTER(Material)]),
+        "rt_mesh_material_n_unknown": (u32, [vp, u32]),
+        "rt_mesh_material_unknown": (C.c_int, [vp, u32, u32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)]),
         "rt_mesh_free": (None, [vp]),
         "rt_normalize_mesh": (C.c_int, [vp, u32]),
         "rt_camera_default": (None, [C.POINTER(Camera), u32, u32]),

@@ -4,9 +4,9 @@
 // Reference behaviour restated here:
 //   OBJ/MTL   tiny_obj_loader v2.0.0 (/root/reference/tiny_obj_loader.h): float grammar and
 //             arithmetic of tryParseDouble :954-1122, index fix-up :867-907, face triples
-//             :1312-1372, quad split along the shorter diagonal :1701-1813, material keys
-//             :188-247.  Polygons with more than 4 corners are fanned (tiny_obj_loader
-//             ear-clips them; neither fixture mesh has any).
+//             :1312-1372, quad split along the shorter diagonal :1701-1813, the built-in ear
+//             clipping of polygons with more than 4 corners :1945-2191 (+ pnpoly :1616-1628),
+//             material keys :188-247 and unknown_parameter :2749-2762.
 //   normalizeMesh  web/script.js:207-227
 //   uniforms       web/script.js:30-154, 591-612, 880-929 ; layout web/compute.wgsl:4-13
 #include "../../include/rtcore.h"
@@ -25,6 +25,7 @@ struct rt_mesh {
   std::vector<uint32_t> vidx, nidx, tidx;
   std::vector<int32_t> mat_ids;
   std::vector<rt_material> materials;
+  std::vector<std::map<std::string, std::string>> unknown;   // per material: material_t::unknown_parameter
 };
 
 namespace {
@@ -144,10 +145,21 @@ bool parse_corner(const char*& p, int nv, int nvn, int nvt, Corner* c) {
   return true;
 }
 
-void parse_mtl(const std::string& text, std::vector<rt_material>& mats, std::map<std::string, int>& by_name) {
+// keys LoadMtl consumes itself (tiny_obj_loader.h:2385-2747); any other `key<blank>value` line lands in unknown_parameter
+bool mtl_key_known(const std::string& k) {
+  static const char* known[] = {"newmtl", "Ka", "Kd", "Ks", "Kt", "Tf", "Ni", "Ke", "Ns", "illum", "d", "Tr", "Pr", "Pm", "Ps", "Pc", "Pcr",
+                                "aniso", "anisor", "map_Ka", "map_Kd", "map_Ks", "map_Ns", "map_bump", "map_Bump", "bump", "map_d",
+                                "map_disp", "map_Disp", "disp", "refl", "map_Pr", "map_Pm", "map_Ps", "map_Ke", "norm"};
+  for (const char* x : known) if (k == x) return true;
+  return false;
+}
+
+void parse_mtl(const std::string& text, std::vector<rt_material>& mats, std::vector<std::map<std::string, std::string>>& unknown,
+               std::map<std::string, int>& by_name) {
   std::istringstream in(text);
   std::string line;
   rt_material cur;
+  std::map<std::string, std::string> cur_unknown;
   bool have = false;
   auto reset = [&](const std::string& name) {
     std::memset(&cur, 0, sizeof(cur));
@@ -155,12 +167,17 @@ void parse_mtl(const std::string& text, std::vector<rt_material>& mats, std::map
     cur.diffuse[0] = cur.diffuse[1] = cur.diffuse[2] = 0.6f;   // tinyobj InitMaterial leaves 0; Kd is normally present
     cur.dissolve = 1.0f;
     cur.illum = 0;
+    cur_unknown.clear();
   };
-  auto flush = [&]() { if (have) { by_name[cur.name] = (int)mats.size(); mats.push_back(cur); } };
+  auto flush = [&]() { if (have) { by_name[cur.name] = (int)mats.size(); mats.push_back(cur); unknown.push_back(cur_unknown); } };
   while (std::getline(in, line)) {
+    // trailing blanks, then one '\r', go first (tiny_obj_loader.h:2349-2365)
+    line.erase(line.find_last_not_of(" \t") + 1);
+    if (!line.empty() && line.back() == '\r') line.pop_back();
     Cursor c{line.c_str()};
     c.skip_blank();
-    if (*c.p == 0 || *c.p == '#' || *c.p == '\r') continue;
+    if (*c.p == 0 || *c.p == '#') continue;
+    const char* token = c.p;
     std::string key = c.word();
     if (key == "newmtl") { flush(); reset(c.rest()); have = true; }
     else if (!have) continue;
@@ -173,8 +190,82 @@ void parse_mtl(const std::string& text, std::vector<rt_material>& mats, std::map
     else if (key == "map_Bump" || key == "map_bump" || key == "bump") {
       std::snprintf(cur.bump_texname, sizeof(cur.bump_texname), "%s", c.rest().c_str());
     }
+    else if (!mtl_key_known(key)) {
+      // tiny_obj_loader.h:2749-2762: the key ends at the first ' ' of the line (at the first '\t' only when the line has
+      // no ' ' at all), the value is everything behind that one character; map::insert keeps the first value of a key
+      const char* sep = std::strchr(token, ' ');
+      if (!sep) sep = std::strchr(token, '\t');
+      if (sep) cur_unknown.insert(std::make_pair(std::string(token, (size_t)(sep - token)), std::string(sep + 1)));
+    }
   }
   flush();
+}
+
+// Point-in-polygon test of tiny_obj_loader.h:1616-1628 (W. R. Franklin's pnpoly) on a triangle, f32 as there.
+bool point_in_tri(const float vx[3], const float vy[3], float tx, float ty) {
+  bool in = false;
+  for (int i = 0, j = 2; i < 3; j = i++)
+    if (((vy[i] > ty) != (vy[j] > ty)) && (tx < (vx[j] - vx[i]) * (ty - vy[i]) / (vy[j] - vy[i]) + vx[i])) in = !in;
+  return in;
+}
+
+// tinyobj's built-in ear clipping of a polygon with more than 4 corners (tiny_obj_loader.h:1945-2191), f32 arithmetic:
+//   * work plane: the first corner triple (k, k+1, k+2) whose edge cross product has a component above FLT_EPSILON picks
+//     the two axes - |cx| largest: (y, z); |cz| largest: (x, y); otherwise (x, z); no such corner: (y, z);
+//   * a candidate ear (g, g+1, g+2) of the remaining ring is skipped when cross * area < 0, where cross is the 2-D cross
+//     product of its two edges and "area" is HALF THE CROSS PRODUCT OF THE POSITION VECTORS of its first two corners (so
+//     the result depends on where the polygon sits relative to the origin - restated as it is), or when any other
+//     remaining corner lies inside it (point_in_tri);
+//   * an ear emits (g, g+1, g+2) and drops g+1; g does not advance; the search gives up after a full round without
+//     progress (the corners still left are dropped, as there); the last three corners are emitted as they stand.
+// P: positions (3 floats per vertex); vidx[i]: position index of corner i; tris: corner numbers, 3 per triangle.
+void ear_clip(const float* P, const std::vector<int>& vidx, std::vector<int>& tris) {
+  const size_t n = vidx.size();
+  size_t axes[2] = {1, 2};
+  for (size_t k = 0; k < n; ++k) {
+    const float* a = P + 3 * (size_t)vidx[k % n];
+    const float* b = P + 3 * (size_t)vidx[(k + 1) % n];
+    const float* c = P + 3 * (size_t)vidx[(k + 2) % n];
+    const float e0x = b[0] - a[0], e0y = b[1] - a[1], e0z = b[2] - a[2];
+    const float e1x = c[0] - b[0], e1y = c[1] - b[1], e1z = c[2] - b[2];
+    const float cx = std::fabs(e0y * e1z - e0z * e1y), cy = std::fabs(e0z * e1x - e0x * e1z), cz = std::fabs(e0x * e1y - e0y * e1x);
+    const float eps = 1.1920928955078125e-07f;   // std::numeric_limits<float>::epsilon()
+    if (cx > eps || cy > eps || cz > eps) {
+      if (!(cx > cy && cx > cz)) {
+        axes[0] = 0;
+        if (cz > cx && cz > cy) axes[1] = 1;
+      }
+      break;
+    }
+  }
+  std::vector<int> ring(n);                        // corner numbers still in the polygon
+  for (size_t i = 0; i < n; ++i) ring[i] = (int)i;
+  size_t guess = 0, budget = n, prev = n;
+  while (ring.size() > 3 && budget > 0) {
+    const size_t m = ring.size();
+    if (guess >= m) guess -= m;
+    if (prev != m) { prev = m; budget = m; } else budget--;
+    int corner[3];
+    float vx[3], vy[3];
+    for (int k = 0; k < 3; ++k) {
+      corner[k] = ring[(guess + k) % m];
+      vx[k] = P[3 * (size_t)vidx[corner[k]] + axes[0]];
+      vy[k] = P[3 * (size_t)vidx[corner[k]] + axes[1]];
+    }
+    const float e0x = vx[1] - vx[0], e0y = vy[1] - vy[0], e1x = vx[2] - vx[1], e1y = vy[2] - vy[1];
+    const float cross = e0x * e1y - e0y * e1x;
+    const float area = (vx[0] * vy[1] - vy[0] * vx[1]) * 0.5f;
+    if (cross * area < 0.0f) { guess += 1; continue; }
+    bool overlap = false;
+    for (size_t other = 3; other < m && !overlap; ++other) {
+      const int o = ring[(guess + other) % m];
+      overlap = point_in_tri(vx, vy, P[3 * (size_t)vidx[o] + axes[0]], P[3 * (size_t)vidx[o] + axes[1]]);
+    }
+    if (overlap) { guess += 1; continue; }
+    tris.push_back(corner[0]); tris.push_back(corner[1]); tris.push_back(corner[2]);
+    ring.erase(ring.begin() + (ptrdiff_t)((guess + 1) % m));
+  }
+  if (ring.size() == 3) { tris.push_back(ring[0]); tris.push_back(ring[1]); tris.push_back(ring[2]); }
 }
 
 void set_err(char* err, size_t n, const std::string& msg) { if (err && n) std::snprintf(err, n, "%s", msg.c_str()); }
@@ -183,7 +274,7 @@ int parse_obj(const std::string& text, const std::string* mtl_text, const std::s
               rt_mesh** out, char* err, size_t err_len) {
   auto* m = new rt_mesh();
   std::map<std::string, int> mat_by_name;
-  if (mtl_text) parse_mtl(*mtl_text, m->materials, mat_by_name);
+  if (mtl_text) parse_mtl(*mtl_text, m->materials, m->unknown, mat_by_name);
   std::vector<Corner> face;
   int cur_mat = -1;
   size_t line_no = 0;
@@ -250,7 +341,10 @@ int parse_obj(const std::string& text, const std::string* mtl_text, const std::s
         if (s02 < s13) { emit(0, 1, 2); emit(0, 2, 3); }
         else { emit(0, 1, 3); emit(1, 2, 3); }
       } else {
-        for (size_t i = 1; i + 1 < n; ++i) emit(0, (int)i, (int)i + 1);
+        std::vector<int> vi(n), tris;
+        for (size_t i = 0; i < n; ++i) vi[i] = face[i].v;
+        ear_clip(m->pos.data(), vi, tris);
+        for (size_t i = 0; i + 2 < tris.size(); i += 3) emit(tris[i], tris[i + 1], tris[i + 2]);
       }
     } else if (!strncmp(t, "usemtl", 6) && is_blank(t[6])) {
       c.p = t + 7;
@@ -264,7 +358,7 @@ int parse_obj(const std::string& text, const std::string* mtl_text, const std::s
         std::ifstream f(mtl_dir + "/" + fn, std::ios::binary);
         if (f) {
           std::stringstream ss; ss << f.rdbuf();
-          parse_mtl(ss.str(), m->materials, mat_by_name);
+          parse_mtl(ss.str(), m->materials, m->unknown, mat_by_name);
         }  // a missing .mtl is a warning, not an error (tiny_obj_loader behaviour)
       }
     }
@@ -324,6 +418,16 @@ extern "C" int rt_mesh_view_get(const rt_mesh* m, rt_mesh_view* v) {
 extern "C" int rt_mesh_material(const rt_mesh* m, uint32_t i, rt_material* out) {
   if (!m || !out || i >= m->materials.size()) return RT_ERR_INVALID;
   *out = m->materials[i];
+  return RT_OK;
+}
+extern "C" uint32_t rt_mesh_material_n_unknown(const rt_mesh* m, uint32_t i) {
+  return (m && i < m->unknown.size()) ? (uint32_t)m->unknown[i].size() : 0u;
+}
+extern "C" int rt_mesh_material_unknown(const rt_mesh* m, uint32_t i, uint32_t k, const char** key, const char** value) {
+  if (!m || !key || !value || i >= m->unknown.size() || k >= m->unknown[i].size()) return RT_ERR_INVALID;
+  auto it = m->unknown[i].begin();
+  std::advance(it, k);
+  *key = it->first.c_str(); *value = it->second.c_str();
   return RT_OK;
 }
 extern "C" void rt_mesh_free(rt_mesh* m) { delete m; }

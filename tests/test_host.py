@@ -81,7 +81,7 @@ f 1 2 3 4 5
 f 1 2
 """
     m = rt.parse_obj(txt)
-    # 5 triangles + quad (2) + pentagon fan (3); the 2-corner face is dropped
+    # 5 triangles + quad (2) + pentagon (3 ears, here the same as a fan: see test_polygon_ear_clipping); the 2-corner face is dropped
     assert m.n_tri == 10
     assert list(m.positions[4]) == [np.float32(-0.5), np.float32(3.0), np.float32(0.1)]
     assert list(m.vert_idx[:15]) == [0, 1, 2] * 5                      # incl. the negative (relative) indices
@@ -100,6 +100,76 @@ def test_quad_split_other_diagonal(rt):
     m = rt.parse_obj("v 0 0 0\nv 1 0 0\nv 3 3 0\nv 0 1 0\nf 1 2 3 4\n")
     # |v3-v1|^2 = 18 >= |v4-v2|^2 = 2 -> [0,1,3],[1,2,3]
     assert list(m.vert_idx) == [0, 1, 3, 1, 2, 3]
+
+
+def _tris(m):
+    return [tuple(int(v) for v in m.vert_idx[3 * i:3 * i + 3]) for i in range(m.n_tri)]
+
+
+def test_polygon_ear_clipping_convex_pentagon(rt):
+    """tinyobj's built-in ear clipping (tiny_obj_loader.h:1945-2191), worked by hand.  Convex CCW pentagon in z = 0 that does
+    NOT touch the origin: P0(1,1) P1(3,1) P2(4,3) P3(2,4) P4(0,3).
+    axes: corner (P0,P1,P2): e0 = (2,0,0), e1 = (1,2,0) -> |cross| = (0, 0, 4): z largest -> work in (x, y).
+    g = 0: ear (P0,P1,P2): cross = 2*2 - 0*1 = 4, "area" = (x0*y1 - y0*x1)/2 = (1*1 - 1*3)/2 = -1 -> cross*area < 0: skipped, g = 1.
+    g = 1: ear (P1,P2,P3): e0 = (1,2), e1 = (-2,1): cross = 5, area = (3*3 - 1*4)/2 = 2.5; P4 and P0 lie outside -> emit (1,2,3),
+           drop P2: ring P0 P1 P3 P4.
+    g = 1: ear (P1,P3,P4): e0 = (-1,3), e1 = (-2,-1): cross = 7, area = (3*4 - 1*2)/2 = 5; P0 outside -> emit (1,3,4), drop P3.
+    rest: (0,1,4).  (A fan from P0 - what this parser did before - gives (0,1,2),(0,2,3),(0,3,4).)"""
+    m = rt.parse_obj("v 1 1 0\nv 3 1 0\nv 4 3 0\nv 2 4 0\nv 0 3 0\nf 1 2 3 4 5\n")
+    assert _tris(m) == [(1, 2, 3), (1, 3, 4), (0, 1, 4)]
+
+
+def test_polygon_ear_clipping_concave_hexagon(rt):
+    """L-shaped hexagon in the plane x = 2, (y, z) = Q0(0,0) Q1(4,0) Q2(4,4) Q3(3,4) Q4(3,1) Q5(0,1); Q4 is the reflex corner.
+    axes: corner (Q0,Q1,Q2): e0 = (0,4,0), e1 = (0,0,4) -> |cross| = (16, 0, 0): x largest -> work in (y, z).
+    g = 0: (Q0,Q1,Q2): cross = 16, area = 0 -> candidate; Q4(3,1) is inside the triangle (0,0),(4,0),(4,4) -> overlap, g = 1.
+    g = 1: (Q1,Q2,Q3) = (4,0),(4,4),(3,4): cross = 0*0 - 4*(-1) = 4, area = (4*4 - 0*4)/2 = 8; Q4, Q5, Q0 outside -> emit (1,2,3);
+           ring Q0 Q1 Q3 Q4 Q5.
+    g = 1: (Q1,Q3,Q4) = (4,0),(3,4),(3,1): cross = (-1)(-3) - 4*0 = 3, area = (4*4 - 0*3)/2 = 8; Q5, Q0 outside -> emit (1,3,4);
+           ring Q0 Q1 Q4 Q5.
+    g = 1: (Q1,Q4,Q5) = (4,0),(3,1),(0,1): cross = (-1)*0 - 1*(-3) = 3, area = (4*1 - 0*3)/2 = 2; Q0 outside -> emit (1,4,5).
+    rest: (0,1,5).  Areas 2 + 1.5 + 1.5 + 2 = 7 = the L's area (4x1 + 1x3): nothing outside the polygon is covered,
+    which a fan from Q0 would do."""
+    m = rt.parse_obj("v 2 0 0\nv 2 4 0\nv 2 4 4\nv 2 3 4\nv 2 3 1\nv 2 0 1\nf 1 2 3 4 5 6\n")
+    assert _tris(m) == [(1, 2, 3), (1, 3, 4), (1, 4, 5), (0, 1, 5)]
+    P = m.positions.astype(np.float64)
+    area = sum(0.5 * np.linalg.norm(np.cross(P[b] - P[a], P[c] - P[a])) for a, b, c in _tris(m))
+    assert area == 7.0
+
+
+def test_polygon_ear_clipping_collinear_points(rt):
+    """Pentagon in the plane y = 0 whose first three corners are collinear: (x, z) = R0(1,1) R1(2,1) R2(3,1) R3(3,3) R4(1,3).
+    axes: corner (R0,R1,R2) has a zero cross product and is passed over; corner (R1,R2,R3): e0 = (1,0,0), e1 = (0,0,2) ->
+          |cross| = (0, 2, 0): neither x nor z is largest -> work in (x, z).
+    g = 0: (R0,R1,R2): cross = 0 -> cross*area = 0 is not < 0, no other corner inside the (empty) triangle -> tinyobj emits the
+           DEGENERATE triangle (0,1,2) and drops R1; ring R0 R2 R3 R4.
+    g = 0: (R0,R2,R3) = (1,1),(3,1),(3,3): cross = 4, area = (1*1 - 1*3)/2 = -1 -> skipped, g = 1.
+    g = 1: (R2,R3,R4) = (3,1),(3,3),(1,3): cross = 0*0 - 2*(-2) = 4, area = (3*3 - 1*3)/2 = 3; R0 outside -> emit (2,3,4).
+    rest: (0,2,4)."""
+    m = rt.parse_obj("v 1 0 1\nv 2 0 1\nv 3 0 1\nv 3 0 3\nv 1 0 3\nf 1 2 3 4 5\n")
+    assert _tris(m) == [(0, 1, 2), (2, 3, 4), (0, 2, 4)]
+    # normals / texcoords / materials follow the corners
+    m = rt.parse_obj("v 1 0 1\nv 2 0 1\nv 3 0 1\nv 3 0 3\nv 1 0 3\nvn 0 1 0\nvn 0 0 1\nvt 0 0\nvt 1 1\n"
+                     "usemtl a\nf 1/1/1 2/2/2 3/1/1 4/2/2 5/1/1\n", "newmtl a\nKd 1 0 0\n")
+    assert list(m.norm_idx) == [0, 1, 0, 0, 1, 0, 0, 0, 0] and list(m.tex_idx) == [0, 1, 0, 0, 1, 0, 0, 0, 0]
+    assert list(m.material_ids) == [0, 0, 0]
+
+
+def test_mtl_unknown_parameters_are_kept(rt):
+    """material_t::unknown_parameter (tiny_obj_loader.h:2749-2762): a line whose key tinyobj has no field for is stored as
+    key -> rest of the line; the key ends at the first ' ' (at the first tab only when the line holds no ' '), the value
+    is everything behind that ONE character (leading blanks stay, trailing blanks of the line are trimmed before), the
+    first value of a repeated key wins, keys come back in std::map order; keys tinyobj parses itself (Ka, Ns, Ni, Pr, ...)
+    are not unknown even where this library keeps no field for them."""
+    mtl = ("newmtl a\nKd 1 0 0\nKa 0.1 0.1 0.1\nNs 10\nNi 1.5\nPr 0.5\nzeta  two  words  \nalpha 1\nalpha 2\n"
+           "tab\tsep\nmixed\tkey val\nnovalue\n# comment\n"
+           "newmtl b\nmap_Kd t.png\nfoo bar\n")
+    m = rt.parse_obj("v 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl a\nf 1 2 3\n", mtl)
+    a, b = m.materials
+    assert a["unknown_parameter"] == {"alpha": "1", "mixed\tkey": "val", "tab": "sep", "zeta": " two  words"}
+    assert list(a["unknown_parameter"]) == ["alpha", "mixed\tkey", "tab", "zeta"]
+    assert b["unknown_parameter"] == {"foo": "bar"} and b["map_Kd"] == "t.png"
+    assert a["diffuse"] == (1.0, 0.0, 0.0)
 
 
 def test_obj_errors(rt):
