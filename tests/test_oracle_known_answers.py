@@ -126,3 +126,62 @@ def test_quad_center_pixel(oracle, rt):             # SURVEY §8c quad known ans
     assert a == 255 and bl == 0 and r > g > 0
     assert abs(int(r) - round(255 * (1 / math.sqrt(3)) ** (1 / 2.2))) <= 60   # + indirect (quad sees no other geometry => 0)
     assert int(r) == round(255 * (1 / math.sqrt(3)) ** (1 / 2.2))
+
+
+def _derivation():
+    import importlib.util
+    import os
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "derive_known_answers.py")
+    spec = importlib.util.spec_from_file_location("derive_known_answers", p)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_soft_shadow_pixel_worked_in_float64(oracle):
+    """computeDirectRadiance_OS_fast (compute.wgsl:199-256) on a tilted receiver under a small occluder, worked in float64 by
+    tests/golden/derive_known_answers.py (no oracle / library code in it): pixel (4, 3) of an 8 x 8 frame hits the receiver at
+    t = 4.92555...; of the four stratified directions (cells 0..3 of the 6 x 6 grid) all are `visible` (cos to the light
+    0.831, 0.827, 0.868, 0.591 > 0.5), samples 1 and 2 hit the occluder, 0 and 3 pass it: occ = 2, shadowFactor = 0.5,
+    direct = 0.7824 * 0.5, colour = pow((1, 0.84, 0) * 0.3912, 1/2.2) -> (166, 154, 0, 255)."""
+    d = _derivation()
+    a = d.case_a()
+    assert a["hit_tri"] == 1 and a["occ"] == 2 and a["shadow_factor"] == 0.5
+    assert [(s["visible"], s["hits_occluder"]) for s in a["samples"]] == [(True, False), (True, True), (True, True), (True, False)]
+    assert min(abs(s["cos_to_light"] - 0.5) for s in a["samples"]) > 0.05            # no flag sits on its threshold
+    assert a["rgba8"] == [166, 154, 0, 255]
+    nodes, tp, tn = d.flat_buffers()
+    out, _ = oracle.render(nodes, tp, tn, d.uniforms(d.LIGHT_A), mode=oracle.MODE_SHADOW, gi_samples=32, soft_samples=4)
+    x, y = a["pixel"]
+    assert out["hit_tri"][y, x] == 1
+    assert abs(float(out["hit_t"][y, x]) - a["hit_t"]) < 2e-6 * a["hit_t"]
+    assert list(out["rgba8"][y, x]) == a["rgba8"]
+    # the jitters are the PRNG's: sample 0's first one by hand - seed.x = f32(28 + 17) + f32(hash_u32(0)) = 3232319744 (45 is
+    # below half an ulp of 256), so xi saturates to 0xFFFFFFFF; seed.y = 0.37: yi = u32(0.37f * 199999 + 1423) = 75422
+    mix = 0xFFFFFFFF ^ (75422 >> 6) ^ ((75422 << 11) & 0xFFFFFFFF)
+    assert a["samples"][0]["jitter"][0] == float(np.float32(np.float32(oracle.hash_u32(mix)) * np.float32(1.0 / 4294967296.0)))
+    assert a["samples"][0]["jitter"][0] == oracle.rand2(3232319744.0, 0.37)
+
+
+def test_path_traced_pixel_worked_in_float64(oracle):
+    """computeLighting_optimized (compute.wgsl:344-410) with GI_SAMPLES = 2, GI_BOUNCES = 1, summed by hand in the same script:
+    both bounce rays of pixel (4, 3) land on the large occluder's underside (t = 2.1143, 2.0881), whose direct terms are
+    unshadowed (its own shadow rays leave it downwards): dS = 0.31935 and 0.18188, so
+        indirect = (1, 0.84, 0) * (0.31935 + 0.18188) / 2 = (0.25061, 0.21052, 0);
+    the primary hit's direct term on the 2 x 1 grid: samples 0..2 visible, 3 not (cos 0.016), only sample 1 hits the occluder:
+        occ = 1, direct = 0.43269 * 0.75 = 0.32452;   col = albedo * direct + indirect = (0.57513, 0.48311, 0) -> (198, 183, 0, 255)."""
+    d = _derivation()
+    b = d.case_b()
+    assert [r["hit_tri"] for r in b["bounces"]] == [0, 0] and [r["occ"] for r in b["bounces"]] == [0, 0]
+    assert abs(b["bounces"][0]["direct"] - 0.31935) < 1e-5 and abs(b["bounces"][1]["direct"] - 0.18188) < 1e-5
+    assert b["primary_occ"] == 1 and [(s["visible"], s["hits_occluder"]) for s in b["primary_samples"]] == \
+        [(True, False), (True, True), (True, False), (False, False)]
+    assert abs(b["col"][0] - (0.43269354682593947 * 0.75 + (0.3193483303026445 + 0.1818793674219388) / 2)) < 1e-12
+    assert b["rgba8"] == [198, 183, 0, 255]
+    nodes, tp, tn = d.flat_buffers()
+    out, st = oracle.render(nodes, tp, tn, d.uniforms(d.LIGHT_B), mode=oracle.MODE_PT, gi_samples=2, gi_bounces=1, soft_samples=4,
+                            rows=(3, 4, 1))
+    x, y = b["pixel"]
+    assert out["hit_tri"][y, x] == 1
+    assert list(out["rgba8"][y, x]) == b["rgba8"]
+    assert st["rays_bounce"] > 0 and st["rays_shadow"] > 0
