@@ -122,9 +122,14 @@ def main():
         ctx.set_mesh(mesh)
         if textured:
             ctx.set_surface(mesh)       # texcoords + material ids: reordered into BVH order by every build below
-        runs = [ctx.build_lbvh() for _ in range(5)]
+        runs, walls = [], []
+        for _ in range(5):
+            t_b = time.perf_counter()
+            runs.append(ctx.build_lbvh())          # returns after the build's one read-back: the tree is usable
+            walls.append((time.perf_counter() - t_b) * 1e3)
         runs.sort(key=lambda s: s["ms_total"])
         build = runs[len(runs) // 2]
+        build_wall_ms = sorted(walls)[len(walls) // 2]
     bcast_ms = 0.0
     keep = None
     if world > 1:
@@ -296,6 +301,7 @@ def main():
                        "mode": args.mode, "rays_per_frame": int(total_rays), "rays_traced_per_frame": int(total_traced), "frames_in_flight": fif, "frames_per_pipeline": batch, "stripes": "16-row round-robin" if world > 1 else "none",
                        "exchange": ("gather to rank 0" if args.exchange == "root" else "all_gather") if world > 1 else "none"},
             "lbvh_build_ms": {k: round(float(v), 4) for k, v in build.items() if k.startswith("ms_")},
+            "lbvh_build_wall_ms": round(build_wall_ms, 4),     # host clock around rt_build_lbvh (launches + events + the read-back)
             "lbvh_build_roofline_frac": round(build["algorithmic_bytes"] / (build["ms_total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
             "bvh_broadcast_ms": round(bcast_ms, 3),
             "frame_kernels_ms": round(kernel_ms, 4), "frame_kernels_ms_max_rank": round(kernel_max, 4),

@@ -85,7 +85,7 @@ int  rt_mesh_parse_obj(const char* obj_text, size_t obj_len, const char* mtl_tex
 int  rt_mesh_view_get(const rt_mesh* m, rt_mesh_view* out);
 int  rt_mesh_material(const rt_mesh* m, uint32_t i, rt_material* out);
 /* material_t::unknown_parameter (tiny_obj_loader.h:247, filled at :2749-2762): the `key value` lines of the MTL that
- * tinyobj has no field for, in std::map order (sorted by key; the first value of a repeated key wins).  The strings
+ * tinyobj has no field for, in the order of its ordered map (sorted by key; the first value of a repeated key wins).  The strings
  * live as long as the mesh. */
 uint32_t rt_mesh_material_n_unknown(const rt_mesh* m, uint32_t i);
 int  rt_mesh_material_unknown(const rt_mesh* m, uint32_t i, uint32_t k, const char** key, const char** value);
@@ -128,10 +128,15 @@ int rt_set_node_encoding(rt_ctx* ctx, int encoding);
 int rt_get_node_encoding(rt_ctx* ctx);   /* of the current BVH if there is one, else the setting */
 
 typedef struct rt_build_stats {
-  float ms_bounds, ms_morton, ms_sort, ms_tree, ms_refit, ms_pack, ms_total;  /* hipEvent times */
+  /* hipEvent times of the build's stages: ms_bounds = centroid bounds; ms_morton = codes + the sort's digit histograms;
+   * ms_sort = the three 10-bit onesweep passes; ms_refit = leaf records, triangle buffers and every node whose leaves
+   * lie inside one 256-leaf block (Karras search + boxes, k_refit_local); ms_tree = the nodes that span blocks (their
+   * Karras search and boxes, k_refit_mid + k_refit_spans); ms_pack = 0 for builds (the traversal records are written by
+   * the refit kernels; only imported trees are packed). */
+  float ms_bounds, ms_morton, ms_sort, ms_tree, ms_refit, ms_pack, ms_total;
   uint32_t n_tri, n_nodes;
   uint64_t algorithmic_bytes;   /* 560 B x n_tri */
-  uint32_t refit_fallbacks;     /* times (this context) the fence-free refit hand-off failed verification and was redone fenced */
+  uint32_t refit_fallbacks;     /* always 0 since round 2: the refit has no hand-off between workgroups left that could fail (kept for ABI stability) */
 } rt_build_stats;
 
 /* Replaces buildLBVH(raw, 1) + flattenForSSBO (script.js:729-730) with the Morton LBVH the

@@ -1,8 +1,10 @@
 // rt_trace.hip — hot path 2: per-pixel ray/scene loop of web/compute.wgsl as a persistent-
 // thread, wave64 traversal kernel for gfx950.
 //
-// One lane = one pixel of an 8x8 tile; each wave pulls tiles from a global atomic counter
-// until the frame (or this rank's stripes) is drained.  The traversal stack lives in LDS
+// A frame is three launches: k_cull (pixels whose primary ray misses the root box are final), k_compact (the others go
+// into a pixel list, hottest cost class first) and the persistent k_render: one lane = one list entry, each wave pulls
+// 64-entry chunks from 64 sharded queue heads (home shard by XCD, then stealing) until the list - one frame's, this
+// rank's stripes', or the lists of a whole batch of frames - is drained.  The traversal stack lives in LDS
 // ([entry][thread], conflict-free) so that dynamic indexing never spills to scratch.
 //
 // Two node layouts (A/B, same results bit for bit):
