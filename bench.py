@@ -155,7 +155,9 @@ def main():
     shade = dict(gi_samples=shade.gi_samples, gi_bounces=shade.gi_bounces, soft_samples=shade.soft_samples, max_stack=shade.max_stack)
     base = rt.render_opts(mode=mode, layout=layout, flags=tflag, **shade)
     fif = (1 if world == 1 else 3) if args.frames_in_flight == "auto" else int(args.frames_in_flight)
-    batch = 8 if args.batch == "auto" else int(args.batch)
+    batch = (1 if frag else 8) if args.batch == "auto" else int(args.batch)     # the older fragment shaders run one frame per pipeline
+    if frag and batch > 1:
+        raise SystemExit("--batch > 1 renders through rt_render_batch_device: --mode primary|shadow|pt only")
     if batch > 1:
         fif = 1                         # a batch is its own overlap: it runs on the context stream
     frame = rdist.ShardedFrame(rdist.GpuBackend(ctx, device, frames_in_flight=fif), W, H, rank, world, base, exchange=args.exchange)
@@ -276,7 +278,7 @@ def main():
     total_rays, total_bytes, total_traced = float(tot[0]), float(tot[1]), float(tot[4])
 
     if rank == 0:
-        pmc = pmc_traffic(args, world, textured)
+        pmc = pmc_traffic(args, world, textured, batch, frames_per_launch)
         ms_per_step = elapsed / args.steps * 1e3
         value = total_rays * args.steps / elapsed / 1e6
         # roofline of the dominant kernel (traversal): this rank's algorithmic bytes / its average launch duration
@@ -333,7 +335,7 @@ def main():
     ctx.close()
 
 
-def pmc_traffic(args, world, textured):
+def pmc_traffic(args, world, textured, batch, frames_per_launch):
     """HBM bytes per k_render launch from the PMC passes (scripts/pmc_passes.sh -> scripts/pmc_summary.py,
     2 x FETCH_SIZE + WRITE_SIZE per MI355X_MICROARCH.md), committed as profiles/traffic.json.  The counters
     need rocprofv3 runs of their own, so the figure is read back from the last committed collection and is
@@ -349,7 +351,11 @@ def pmc_traffic(args, world, textured):
             and bool(w.get("textured", False)) == textured)
     if not same:
         return {}
-    return {"k_render_hbm_bytes_per_launch": t.get("k_render_hbm_bytes_per_launch"), "k_render_valu_lane_util": t.get("k_render_valu_lane_util"),
+    if int(w.get("frames_per_pipeline", 1)) != batch:
+        return {}
+    # counters are per launch of the collection run; this run's launches may hold another number of frames (K = 20 -> 8 + 8 + 4)
+    per_frame = t.get("k_render_hbm_bytes_per_launch", 0) / max(float(t.get("frames_per_launch", 1.0)), 1e-9)
+    return {"k_render_hbm_bytes_per_launch": int(per_frame * frames_per_launch), "k_render_valu_lane_util": t.get("k_render_valu_lane_util"),
             "source": "profiles/traffic.json: " + str(t.get("source", ""))}
 
 

@@ -5,9 +5,9 @@ set -e
 R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/refresh"; rm -rf "$O"; mkdir -p "$O"
 cd "$R"
 echo "[1] gpu tests"; timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > "$O/gpu_tests.log" 2>&1; tail -1 "$O/gpu_tests.log"
-echo "[2] default bench line"; timeout -k 10 300 python bench.py > "$O/bench_n1.json" 2> "$O/bench_n1.err"
+echo "[2] the driver's bench line"; timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 > "$O/bench_n1.json" 2> "$O/bench_n1.err"
 echo "[3] kernel trace"; scripts/kernel_stats.sh gpurun_out/refresh/ks > "$O/ks.txt" 2>&1; cd "$R"
-echo "[4] pmc passes"; scripts/pmc_passes.sh "$O/pmc" --steps 5 --warmup 3 > "$O/pmc.txt" 2>&1; cd "$R"
+echo "[4] pmc passes"; scripts/pmc_passes.sh "$O/pmc" --steps 20 --warmup 5 > "$O/pmc.txt" 2>&1; cd "$R"
 python3 scripts/pmc_summary.py "$O/pmc" "$O/traffic_all.json" > "$O/pmc_summary.txt"
 echo "[5] variants"
 b() { name=$1; shift; timeout -k 10 400 python bench.py --no-cpu-baseline "$@" > "$O/bench_$name.json" 2> "$O/bench_$name.err"; echo "  $name done"; }
@@ -19,4 +19,11 @@ b s70k_1080p --scene s70k --width 1920 --height 1080 --mode primary
 RTCORE_PT_SPLIT=0 b pt16_unsplit --mode pt --spp 16 --steps 10
 echo "[6] cfg 5"; timeout -k 10 500 python bench.py --no-cpu-baseline --scene lattice76 --width 7680 --height 4320 --steps 10 > "$O/bench_cfg5_100Mtri_8k.json" 2> "$O/bench_cfg5.err"
 echo "[7] frag"; b frag_root --mode frag-root --steps 10; b frag_web --mode frag-web --steps 5
+echo "[8] build kernels"; scripts/build_stats.sh gpurun_out/refresh/build s1m 20 > "$O/build_stats.txt" 2>&1; cd "$R"
+timeout -k 10 120 python -u tools/build_only.py s1m 30 nosurface > "$O/build_nosurface.txt" 2>&1
+timeout -k 10 300 python -u tools/build_only.py lattice76 6 nosurface > "$O/build_cfg5.txt" 2>&1
+echo "[9] batches, scaling projection"; timeout -k 10 300 python -u tools/batch_gain.py > "$O/batch_gain.txt" 2>&1
+timeout -k 10 300 python -u tools/batch_gain.py --moving > "$O/batch_gain_moving.txt" 2>&1
+PROJ_BATCH=8 timeout -k 10 300 python -u tools/project_scaling.py > "$O/project_scaling_batch8.txt" 2>&1
+PROJ_BATCH=1 timeout -k 10 300 python -u tools/project_scaling.py > "$O/project_scaling_per_frame.txt" 2>&1
 echo done

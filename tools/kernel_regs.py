@@ -6,6 +6,7 @@ FLAGS = "--offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-
 
 def main():
     src, flt = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "")
+    FLAGS.extend(sys.argv[3:])          # extra compiler flags, e.g. -DRT_SORT_KPT=20
     r = subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"],
                        capture_output=True, text=True)
     cur, rows = None, []
