@@ -388,7 +388,12 @@ def cpu_baseline(args, mesh, U, mode, textured, shade):
         rays += st["rays_primary"] + st["rays_shadow"] + st["rays_bounce"]
         secs += st["seconds"]
         reps += 1
+    # the same oracle on ONE thread, on every 16th row of that sample (~1/16 of its work)
+    _, s1 = oracle.render(b["nodes"], b["tri_pos"], b["tri_nor"], U, mode=mode, **shade, rows=(0, H, step * 16),
+                          n_threads=1, want=(), encoding=enc, surface=surf)
+    single = (s1["rays_primary"] + s1["rays_shadow"] + s1["rays_bounce"]) / max(s1["seconds"], 1e-9) / 1e6
     return {"value": round(rays / secs / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "single_thread_value": round(single, 3),
             "sample": f"rows 0..{H} step {step} of the same {args.width}x{H} frame ({len(range(0, H, step))} rows) x {reps} "
                       f"repeats: {rays} rays in {secs:.2f} s wall on {cores} threads ({secs * cores:.1f} s of CPU work)",
             "lbvh_build_ms": round(b["seconds"] * 1e3, 2), "lbvh_build_cores": 1}

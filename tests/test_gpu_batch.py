@@ -135,6 +135,10 @@ def test_batch_rejects_what_it_does_not_define(rt, plane_mesh):
         ctx.build_lbvh()
         ctx.render_batch_device(np.stack([U, U]), o, None, None, None)   # no outputs at all: runs, writes nothing
         ctx.synchronize()
+        # a rank that owns no rows of the image (more ranks than stripes): nothing to do, no error
+        ctx.render_batch_device(np.stack([U, U]), rt.render_opts(mode=rt.MODE_SHADOW, stripe_rows=64, stripe_rank=1, stripe_world=2),
+                                None, None, None)
+        ctx.synchronize()
         with pytest.raises(rt.RtError) as e:
             ctx.render_batch_device(np.stack([U] * 9), o, None, None, None)
         assert e.value.code == -1 and "n_frames" in str(e.value)

@@ -56,6 +56,45 @@ def test_async_frames_with_forced_collective(gpu_ctx, rt, plane_mesh, nccl_world
     gpu_ctx.set_frames_in_flight(1)
 
 
+@pytest.mark.parametrize("exchange", ["all", "root"])
+def test_batched_frames_with_forced_collective(gpu_ctx, rt, plane_mesh, nccl_world1, exchange):
+    """dist.BatchedFrames (the loop bench.py runs): 3 frames per pipeline, the batch's ONE collective and its de-interleaves on
+    a side stream behind an event while the context stream already traverses the next batch; two buffer sets alternate.
+    Every frame must be the frame of its own uniforms, including a short last batch."""
+    import torch
+
+    from raytracer_amd import dist as rdist
+    gpu_ctx.set_mesh(plane_mesh)
+    gpu_ctx.build_lbvh()
+    w, h = 320, 200
+    opts = rt.render_opts(mode=rt.MODE_SHADOW)
+    dev = torch.device("cuda:0")
+    views = [dict(PLANE_VIEW), dict(PLANE_VIEW, cam_pos=(0.1, 0.0, 1.2)), dict(PLANE_VIEW, rot_deg=(-70.0, 10.0, 0.0)),
+             dict(PLANE_VIEW, cam_pos=(-0.2, 0.1, 1.0)), dict(PLANE_VIEW, rot_deg=(-80.0, -15.0, 5.0))]
+    Us = [rt.make_uniforms(w, h, **v) for v in views]
+    refs = [gpu_ctx.render(U, opts, want=("rgba8",))[0]["rgba8"] for U in Us]
+    assert len({r.tobytes() for r in refs}) == 5
+    bf = rdist.BatchedFrames(rdist.GpuBackend(gpu_ctx, dev, frames_in_flight=1), w, h, 0, 1, 3, opts, force_collective=True,
+                             exchange=exchange)
+    img = lambda f: bf.images[f].cpu().numpy().view(np.uint8).reshape(h, w, 4)
+    for rounds in range(3):                     # 7 batches queued back to back per round: buffer sets are reused 3 times
+        order = [(0, 1, 2), (3, 4, 0), (1, 2, 3), (4, 0, 1), (2, 3, 4), (0, 2, 4), (1, 3)]
+        for b in order:
+            bf.step(np.stack([Us[k] for k in b]))
+        bf.finish()
+        assert np.array_equal(img(0), refs[1]) and np.array_equal(img(1), refs[3])       # the short last batch
+        assert np.array_equal(img(2), refs[4])                                            # left over from the batch before it
+    # one full batch alone, and the frames after a per-frame call in between
+    bf.step(np.stack([Us[4], Us[3], Us[2]]))
+    bf.finish()
+    assert all(np.array_equal(img(f), refs[k]) for f, k in enumerate((4, 3, 2)))
+    out, _ = gpu_ctx.render(Us[0], opts, want=("rgba8",))
+    assert np.array_equal(out["rgba8"], refs[0])
+    bf.step(np.stack([Us[0], Us[1], Us[2]]))
+    bf.finish()
+    assert all(np.array_equal(img(f), refs[k]) for f, k in enumerate((0, 1, 2)))
+
+
 def test_two_frames_in_flight_without_collective(gpu_ctx, rt, plane_mesh):
     """rt_set_frames_in_flight(2): asynchronous frames alternate between two frame streams and two output buffers; every
     frame must still be the frame of its own uniforms, and synchronous calls in between see finished results."""
