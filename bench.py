@@ -263,7 +263,8 @@ def main():
         views = [rt.make_uniforms(W, H, cam_pos=(0.0, 0.0, 1.3), rot_deg=(0.0, 1.0 * k, 0.0)) for k in range(max(args.steps, 8))]
         cnt = [counted(v) for v in views]
         legs["moving_camera"] = leg(views, [c[0] for c in cnt], [c[3] for c in cnt])
-        legs["moving_camera"]["what"] = "rotY + 1 degree per frame, hints on (tile-level promotion under motion)"
+        legs["moving_camera"]["what"] = ("rotY + 1 degree per frame; a batch whose views differ is not ordered by hints (they would be a batch old)"
+                                         if batch > 1 else "rotY + 1 degree per frame, hints on (tile-level promotion under motion)")
         run_frames([U], 3 * batch)      # leave the context as the main loop had it: hints of the static view
         fence()
 
