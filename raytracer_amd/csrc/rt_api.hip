@@ -1105,9 +1105,21 @@ int render_batch(rt_ctx* ctx, uint32_t n_frames, const float* uniforms, const rt
   p.n_tiles = p.tiles_x * ((p.local_rows + 7) / 8);
   if (p.n_tiles == 0) return RT_OK;                             // this rank owns no rows
   const uint32_t cull_blocks = rt_cull_blocks(p.n_tiles);
-  JOIN_FRAMES();
+  // Pipelines in flight, as render_frame: with rt_set_frames_in_flight(n >= 2) batches rotate over the n frame streams (own
+  // scratch each), so the cull / compaction passes and the head of batch i+1 run beside the tail of batch i.
+  const bool overlap = ctx->frames_in_flight >= 2;
+  int slot = 0;
   hipStream_t s = ctx->stream;
-  const int slot = 0;
+  if (overlap) {
+    slot = (int)(ctx->f_count % (uint32_t)ctx->frames_in_flight);
+    ctx->f_seq[slot] = ctx->f_count++;
+    s = ctx->fstream[slot];
+    HIPCHK(hipEventRecord(ctx->f_main, ctx->stream));
+    HIPCHK(hipStreamWaitEvent(s, ctx->f_main, 0));
+  } else {
+    JOIN_FRAMES();
+  }
+  p.blocks_per_cu_cap = overlap ? 2u : 0u;
   const size_t list_words = ((size_t)p.local_rows * p.width + 63u) & ~(size_t)63u;
   bt.mask_stride = rt_n_class() * p.n_tiles;
   bt.bt_stride = rt_n_class() * cull_blocks;
@@ -1157,6 +1169,10 @@ int render_batch(rt_ctx* ctx, uint32_t n_frames, const float* uniforms, const rt
   rt_launch_render_batch(p, bt, opts->layout, ctx->n_cu, s, E ? E[1] : nullptr, E ? E[2] : nullptr);
   HIPCHK(hipGetLastError());
   if (E) HIPCHK(hipEventRecord(E[3], s));
+  if (overlap) {
+    HIPCHK(hipEventRecord(ctx->f_done[slot], s));
+    ctx->f_pending[slot] = true;
+  }
   return RT_OK;
 }
 }  // namespace

@@ -1412,6 +1412,7 @@ void rt_launch_render_batch(const RtRenderParams& p_in, const RtBatch& bt, int l
   const dim3 b(TBLK), gc(rt_cull_blocks(p.n_tiles), bt.n);
   const void* kernel = render_kernel(layout, false, p.tri_uv != nullptr, KIND_PIXEL, true);
   p.render_blocks = resident_grid(n_cu, p.max_stack, kernel);
+  if (p.blocks_per_cu_cap && !getenv("RTCORE_BLOCKS_PER_CU")) p.render_blocks = std::min(p.render_blocks, (uint32_t)n_cu * p.blocks_per_cu_cap);   // pipelines in flight share the CUs
   hipLaunchKernelGGL((k_cull<true, RtBatch>), gc, b, 0, s, p, batch);
   hipLaunchKernelGGL((k_compact<true, RtBatch>), gc, b, 0, s, p, batch);
   const size_t lds = (size_t)p.max_stack * TBLK * (sizeof(uint32_t) + sizeof(float));

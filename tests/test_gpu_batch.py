@@ -110,6 +110,20 @@ def test_batch_equals_per_frame_rendering(rt, oracle):
         rt_ = _single(ctx, torch, Us, tex)
         assert not np.array_equal(rt_[0], ref[0])
         _same(_batch(ctx, torch, Us, tex), rt_, "textured")
+        # pipelines in flight: batches rotate over the frame streams (own scratch each); every batch keeps its own frames
+        ctx.set_frames_in_flight(2)
+        sets = [_bufs(torch, 5, 271, 483) for _ in range(4)]
+        Uk = [[Us[(f + k) % 5] for f in range(5)] for k in range(4)]
+        for rep in range(2):
+            for k in range(4):                                           # four batches queued back to back, two in flight
+                ctx.render_batch_device(np.stack(Uk[k]), shadow, [sets[k][0][f].data_ptr() for f in range(5)],
+                                        [sets[k][1][f].data_ptr() for f in range(5)], [sets[k][2][f].data_ptr() for f in range(5)])
+            ctx.synchronize()
+            for k in range(4):
+                got = [b.cpu().numpy() for b in sets[k]]
+                for f in range(5):
+                    _same([g[f] for g in got], [r[(f + k) % 5] for r in ref], f"two batches in flight, batch {k}, frame {f}, round {rep}")
+        ctx.set_frames_in_flight(1)
         # outputs are optional per array and per frame
         w, h = 483, 271
         rgba, tri, t = _bufs(torch, 5, h, w)

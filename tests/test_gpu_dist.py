@@ -57,7 +57,8 @@ def test_async_frames_with_forced_collective(gpu_ctx, rt, plane_mesh, nccl_world
 
 
 @pytest.mark.parametrize("exchange", ["all", "root"])
-def test_batched_frames_with_forced_collective(gpu_ctx, rt, plane_mesh, nccl_world1, exchange):
+@pytest.mark.parametrize("fif", [1, 2])
+def test_batched_frames_with_forced_collective(gpu_ctx, rt, plane_mesh, nccl_world1, exchange, fif):
     """dist.BatchedFrames (the loop bench.py runs): 3 frames per pipeline, the batch's ONE collective and its de-interleaves on
     a side stream behind an event while the context stream already traverses the next batch; two buffer sets alternate.
     Every frame must be the frame of its own uniforms, including a short last batch."""
@@ -74,7 +75,7 @@ def test_batched_frames_with_forced_collective(gpu_ctx, rt, plane_mesh, nccl_wor
     Us = [rt.make_uniforms(w, h, **v) for v in views]
     refs = [gpu_ctx.render(U, opts, want=("rgba8",))[0]["rgba8"] for U in Us]
     assert len({r.tobytes() for r in refs}) == 5
-    bf = rdist.BatchedFrames(rdist.GpuBackend(gpu_ctx, dev, frames_in_flight=1), w, h, 0, 1, 3, opts, force_collective=True,
+    bf = rdist.BatchedFrames(rdist.GpuBackend(gpu_ctx, dev, frames_in_flight=fif), w, h, 0, 1, 3, opts, force_collective=True,
                              exchange=exchange)
     img = lambda f: bf.images[f].cpu().numpy().view(np.uint8).reshape(h, w, 4)
     for rounds in range(3):                     # 7 batches queued back to back per round: buffer sets are reused 3 times
@@ -93,6 +94,7 @@ def test_batched_frames_with_forced_collective(gpu_ctx, rt, plane_mesh, nccl_wor
     bf.step(np.stack([Us[0], Us[1], Us[2]]))
     bf.finish()
     assert all(np.array_equal(img(f), refs[k]) for f, k in enumerate((0, 1, 2)))
+    gpu_ctx.set_frames_in_flight(1)
 
 
 def test_two_frames_in_flight_without_collective(gpu_ctx, rt, plane_mesh):

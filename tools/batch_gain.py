@@ -52,21 +52,24 @@ def case(name, mesh, W, H, stripe=None, stripe_rows=16):
         e = time.perf_counter() - t0
         _, tr, k = ctx.profile_end()
         report(f"per frame, {fif} in flight", e, tr, k)
+    for fif, sizes in ((1, (2, 4, 8)), (2, (4, 8)), (3, (8,))):
+      ctx.set_frames_in_flight(fif)
+      for B in sizes:
+          ptrs = [bufs[f].data_ptr() for f in range(B)]
+          Ub = [np.stack([views[(i0 + f) % 8] for f in range(B)]) for i0 in range(0, 8, B)]
+          for i in range(4):
+              ctx.render_batch_device(Ub[i % len(Ub)], o, ptrs)
+          (ctx.frames_join(0), ctx.synchronize())
+          ctx.profile_begin()
+          t0 = time.perf_counter()
+          for i in range(n // B):
+              ctx.render_batch_device(Ub[i % len(Ub)], o, ptrs)
+          (ctx.frames_join(0), ctx.synchronize())
+          e = time.perf_counter() - t0
+          _, tr, k = ctx.profile_end()
+          report(f"batch of {B}" + (f", {fif} in flight" if fif > 1 else ""), e, tr, k)
+
     ctx.set_frames_in_flight(1)
-    for B in (2, 4, 8):
-        ptrs = [bufs[f].data_ptr() for f in range(B)]
-        Ub = [np.stack([views[(i0 + f) % 8] for f in range(B)]) for i0 in range(0, 8, B)]
-        for i in range(4):
-            ctx.render_batch_device(Ub[i % len(Ub)], o, ptrs)
-        ctx.synchronize()
-        ctx.profile_begin()
-        t0 = time.perf_counter()
-        for i in range(n // B):
-            ctx.render_batch_device(Ub[i % len(Ub)], o, ptrs)
-        ctx.synchronize()
-        e = time.perf_counter() - t0
-        _, tr, k = ctx.profile_end()
-        report(f"batch of {B}", e, tr, k)
     ctx.close()
 
 
