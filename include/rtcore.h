@@ -256,7 +256,9 @@ int rt_render_device_noalloc(rt_ctx* ctx, const float uniforms[44], const rt_ren
  * lists (the hottest pixels of every frame first), so the launch overheads and the idle tail of a frame are paid once
  * per batch: this is the entry point for small frames / stripe shares (a 1/8 share of a 4K frame is ~0.1 ms of work).
  * RT_MODE_PRIMARY / SHADOW / PT only (PT runs one lane per pixel); no statistics (RT_FLAG_COUNT_WORK is refused);
- * asynchronous on rt_stream(); the scheduling hints left behind are those of the last frame. */
+ * asynchronous on rt_stream() - or, with rt_set_frames_in_flight(n >= 2), on the frame streams under the ordering rules
+ * given there (a batch counts as one frame: the tail of batch i overlaps the head of batch i+1); the scheduling hints
+ * left behind are those of the last frame, and a batch whose views differ is not ordered by hints at all. */
 #define RT_MAX_BATCH 8
 int rt_render_batch_device(rt_ctx* ctx, uint32_t n_frames, const float* uniforms /* [n_frames][44] */, const rt_render_opts* opts,
                            void* const* d_rgba8, void* const* d_hit_tri, void* const* d_hit_t);
