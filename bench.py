@@ -158,8 +158,9 @@ def main():
     if frag and batch > 1:
         raise SystemExit("--batch > 1 renders through rt_render_batch_device: --mode primary|shadow|pt only")
     # pipelines (frames, or batches of frames) in flight: 1 at N = 1, so that every k_render launch runs alone and its duration is
-    # the kernel's own; with N > 1 two batches (three single frames) rotate over the frame streams
-    fif = (1 if world == 1 else (2 if batch > 1 else 3)) if args.frames_in_flight == "auto" else int(args.frames_in_flight)
+    # the kernel's own.  Batches stay at 1 with N > 1 too: a second batch in flight gains 5 % on a 1/8 share of a 4K frame and
+    # loses 27 % on an 8K frame (each pipeline then owns 2 of the 3 resident blocks per CU); single frames use three
+    fif = (1 if (world == 1 or batch > 1) else 3) if args.frames_in_flight == "auto" else int(args.frames_in_flight)
     frame = rdist.ShardedFrame(rdist.GpuBackend(ctx, device, frames_in_flight=fif), W, H, rank, world, base, exchange=args.exchange)
     bframes = rdist.BatchedFrames(frame.b, W, H, rank, world, batch, base, exchange=args.exchange) if batch > 1 else None
 
