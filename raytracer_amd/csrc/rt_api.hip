@@ -816,6 +816,36 @@ int check_opts(rt_ctx* ctx, const rt_render_opts* o) {
 }  // namespace
 
 namespace {
+// What every frame pipeline takes from the context: the tree, the traversal layout, the step budget and (RT_FLAG_TEXTURED) the
+// surface tables.  alloc_tables = false: the no-alloc entry point, which must find the material / texture tables in place.
+int fill_scene_params(rt_ctx* ctx, const rt_render_opts* opts, RtRenderParams& p, bool alloc_tables) {
+  p.nodes = ctx->bvh.nodes; p.tri_pos = ctx->bvh.tri_pos; p.tri_nor = ctx->bvh.tri_nor;
+  p.wide = ctx->bvh.wide; p.tri_pre = ctx->bvh.tri_pre; p.root_ref = ctx->bvh.root_ref; p.leaf_shift = ctx->bvh.leaf_shift;
+  p.nodes_v2 = ctx->bvh.v2 ? 1 : 0;
+  // one budget step per loop iteration of the walk: WIDE64 spends one per internal record AND one per leaf triangle
+  // (closest_wide advances leaf_j one triangle per iteration), AOS32 one per node visit with twice this budget
+  p.step_budget = ctx->bvh.n_nodes + ctx->bvh.n_tri + 64u;
+  if (!(opts->flags & RT_FLAG_TEXTURED)) return RT_OK;
+  if (ctx->tri_uv_n == 0 || ctx->tri_uv_n != ctx->bvh.n_tri)
+    return ctx->fail(RT_ERR_INVALID, "RT_FLAG_TEXTURED: no surface records for the current BVH (rt_set_surface before rt_build_lbvh, or rt_set_tri_uv)");
+  for (uint32_t i = 0; i < ctx->n_materials; ++i) {
+    const int32_t t = ctx->materials_host[i].texture;
+    if (t >= 0 && ((uint32_t)t >= ctx->n_textures || ctx->tex_host[t].texels == nullptr))
+      return ctx->fail(RT_ERR_INVALID, "RT_FLAG_TEXTURED: material " + std::to_string(i) + " names texture slot " + std::to_string(t) + ", which was never set");
+  }
+  if (!alloc_tables) {
+    if (!ctx->materials.p || !ctx->tex_table.p)
+      return ctx->fail(RT_ERR_INVALID, "rt_render_device_noalloc with RT_FLAG_TEXTURED: call rt_set_materials and rt_set_texture first (their tables are not allocated here)");
+  } else {
+    HIPCHK(ctx->materials.ensure(1)); HIPCHK(ctx->tex_table.ensure(RT_MAX_TEXTURES));
+  }
+  p.tri_uv = reinterpret_cast<const float4*>(ctx->tri_uv.p); p.materials = ctx->materials.p; p.textures = ctx->tex_table.p;
+  p.n_materials = ctx->n_materials; p.n_textures = ctx->n_textures;
+  return RT_OK;
+}
+}  // namespace
+
+namespace {
 // frame-coherent scheduling hints: one cost class per pixel of this image shape, cleared whenever the shape, the
 // striping or the BVH changes (hints of another view are merely useless, never wrong: they only order the work)
 // `moved`: the view differs from the last frame's (or, in a batch, between the batch's frames).
@@ -893,29 +923,8 @@ int render_frame(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* op
   DeviceGuard g(ctx->device);
   RtRenderParams p;
   std::memset(&p, 0, sizeof(p));
-  p.nodes = ctx->bvh.nodes; p.tri_pos = ctx->bvh.tri_pos; p.tri_nor = ctx->bvh.tri_nor;
-  p.wide = ctx->bvh.wide; p.tri_pre = ctx->bvh.tri_pre; p.root_ref = ctx->bvh.root_ref; p.leaf_shift = ctx->bvh.leaf_shift;
-  p.nodes_v2 = ctx->bvh.v2 ? 1 : 0;
-  // one budget step per loop iteration of the walk: WIDE64 spends one per internal record AND one per leaf triangle
-  // (closest_wide advances leaf_j one triangle per iteration), AOS32 one per node visit with twice this budget
-  p.step_budget = ctx->bvh.n_nodes + ctx->bvh.n_tri + 64u;
-  if (opts->flags & RT_FLAG_TEXTURED) {
-    if (ctx->tri_uv_n == 0 || ctx->tri_uv_n != ctx->bvh.n_tri)
-      return ctx->fail(RT_ERR_INVALID, "RT_FLAG_TEXTURED: no surface records for the current BVH (rt_set_surface before rt_build_lbvh, or rt_set_tri_uv)");
-    for (uint32_t i = 0; i < ctx->n_materials; ++i) {
-      const int32_t t = ctx->materials_host[i].texture;
-      if (t >= 0 && ((uint32_t)t >= ctx->n_textures || ctx->tex_host[t].texels == nullptr))
-        return ctx->fail(RT_ERR_INVALID, "RT_FLAG_TEXTURED: material " + std::to_string(i) + " names texture slot " + std::to_string(t) + ", which was never set");
-    }
-    if (noalloc) {
-      if (!ctx->materials.p || !ctx->tex_table.p)
-        return ctx->fail(RT_ERR_INVALID, "rt_render_device_noalloc with RT_FLAG_TEXTURED: call rt_set_materials and rt_set_texture first (their tables are not allocated here)");
-    } else {
-      HIPCHK(ctx->materials.ensure(1)); HIPCHK(ctx->tex_table.ensure(RT_MAX_TEXTURES));
-    }
-    p.tri_uv = reinterpret_cast<const float4*>(ctx->tri_uv.p); p.materials = ctx->materials.p; p.textures = ctx->tex_table.p;
-    p.n_materials = ctx->n_materials; p.n_textures = ctx->n_textures;
-  }
+  rc = fill_scene_params(ctx, opts, p, /*alloc_tables=*/!noalloc);
+  if (rc != RT_OK) return rc;
   std::memcpy(p.U, uniforms, sizeof(float) * 44);
   p.mode = opts->mode; p.gi_samples = opts->gi_samples; p.gi_bounces = opts->gi_bounces; p.soft_samples = opts->soft_samples;
   p.max_stack = opts->max_stack;
@@ -1076,22 +1085,8 @@ int render_batch(rt_ctx* ctx, uint32_t n_frames, const float* uniforms, const rt
   DeviceGuard g(ctx->device);
   RtRenderParams p;
   std::memset(&p, 0, sizeof(p));
-  p.nodes = ctx->bvh.nodes; p.tri_pos = ctx->bvh.tri_pos; p.tri_nor = ctx->bvh.tri_nor;
-  p.wide = ctx->bvh.wide; p.tri_pre = ctx->bvh.tri_pre; p.root_ref = ctx->bvh.root_ref; p.leaf_shift = ctx->bvh.leaf_shift;
-  p.nodes_v2 = ctx->bvh.v2 ? 1 : 0;
-  p.step_budget = ctx->bvh.n_nodes + ctx->bvh.n_tri + 64u;      // as render_frame
-  if (opts->flags & RT_FLAG_TEXTURED) {
-    if (ctx->tri_uv_n == 0 || ctx->tri_uv_n != ctx->bvh.n_tri)
-      return ctx->fail(RT_ERR_INVALID, "RT_FLAG_TEXTURED: no surface records for the current BVH (rt_set_surface before rt_build_lbvh, or rt_set_tri_uv)");
-    for (uint32_t i = 0; i < ctx->n_materials; ++i) {
-      const int32_t t = ctx->materials_host[i].texture;
-      if (t >= 0 && ((uint32_t)t >= ctx->n_textures || ctx->tex_host[t].texels == nullptr))
-        return ctx->fail(RT_ERR_INVALID, "RT_FLAG_TEXTURED: material " + std::to_string(i) + " names texture slot " + std::to_string(t) + ", which was never set");
-    }
-    HIPCHK(ctx->materials.ensure(1)); HIPCHK(ctx->tex_table.ensure(RT_MAX_TEXTURES));
-    p.tri_uv = reinterpret_cast<const float4*>(ctx->tri_uv.p); p.materials = ctx->materials.p; p.textures = ctx->tex_table.p;
-    p.n_materials = ctx->n_materials; p.n_textures = ctx->n_textures;
-  }
+  rc = fill_scene_params(ctx, opts, p, /*alloc_tables=*/true);
+  if (rc != RT_OK) return rc;
   std::memcpy(p.U, uniforms, sizeof(float) * 44);               // (the kernels of a batch read bt.U[f])
   p.mode = opts->mode; p.gi_samples = opts->gi_samples; p.gi_bounces = opts->gi_bounces; p.soft_samples = opts->soft_samples;
   p.max_stack = opts->max_stack;
