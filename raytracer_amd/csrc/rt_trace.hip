@@ -1001,6 +1001,7 @@ template <int LAYOUT, bool COUNT, bool TEX, int KIND, bool BATCH = false, typena
 __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p, const B bt) {
   constexpr bool PTSPLIT = KIND == KIND_PTSPLIT;
   static_assert(!BATCH || KIND == KIND_PIXEL, "a batch runs the compute.wgsl pixel kind only");
+  static_assert(RT_MAX_BATCH * N_CLASS <= 64, "a batch's run table (frames x cost classes) is one wavefront wide");
   extern __shared__ __align__(16) unsigned char smem[];
 #ifdef RT_TIMELINE
   const unsigned long long tl_start = wall_clock64();
