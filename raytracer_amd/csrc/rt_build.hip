@@ -533,16 +533,18 @@ RT_DEV void karras_node_wide(const uint32_t* __restrict__ k, const uint32_t* __r
 // No hand-off between workgroups inside a launch.  Node i of the Karras tree covers the contiguous leaf range
 // [lo, hi] of the sorted order, and min / max are exact and order-independent, so a node's box is a RANGE query over the
 // leaf boxes: nothing has to wait for its children.  Three launches, data crossing between them only at kernel boundaries:
-//   k_refit_local   one thread per leaf: BVH-order triangle records, leaf record, then the climb through the nodes whose
-//                   range lies inside the thread's 256-leaf block (k_karras marks them; ~127 of 128 nodes), handing off
-//                   through LDS; the block's own box goes to block_box[]
-//   k_refit_tables  per super-block of 256 blocks (65 536 leaves): sparse table (9 levels) over its block boxes
-//   k_refit_spans   the nodes whose range crosses a block boundary, one wavefront each: the box of a child is read if
-//                   the child is block-local, else folded from the <= 255 leaf boxes at either ragged end of its range,
-//                   <= 4 sparse-table entries and the boxes of whole super-blocks in between
-// (Before: the ~1 % of nodes above the blocks were handed from CU to CU with write-through stores, an atomic counter and
-// sc1 loads per level - a ~70 us latency chain over the top ~12 levels with the chip nearly idle, 2.7x the traffic,
-// and a verify pass + fenced fallback to guard it.)
+//   k_refit_local   one thread per leaf: BVH-order triangle records and the leaf record; the Karras search of every node
+//                   whose range lies inside the thread's 256-leaf block (keys + one halo key per side in LDS: 96.4 % of the
+//                   nodes), their boxes by a climb through LDS, node + wide records written coalesced; the boxes of every
+//                   16-leaf and 64-leaf group, the block's first key; nodes that cross the block boundary go to 64 shard lists
+//   k_refit_mid     blocks [0, ns): per super-block of 256 blocks (65 536 leaves) a sparse table (9 levels) over its block
+//                   boxes; the other blocks: the Karras search of the crossing nodes, 16 lanes per node (KeyProbe above)
+//   k_refit_spans   the crossing nodes' boxes, 16 lanes per node: a child's box is read if the child is block-local or a
+//                   leaf, else folded from <= 16 leaves + <= 3 groups of 16 + <= 3 groups of 64 at either ragged end of its
+//                   range, <= 4 sparse-table entries and the boxes of whole super-blocks in between
+// (Round 1: a separate k_karras, then a climb in which the ~1 % of nodes above the blocks were handed from CU to CU with
+// write-through stores, an atomic counter and sc1 loads per level - a ~70 us latency chain over the top ~12 levels with the
+// chip nearly idle, 2.7x the traffic, and a verify pass + fenced fallback to guard it.)
 static_assert(BLK == 256, "block-local nodes: (lo >> 8) == (hi >> 8)");
 constexpr int CROSS_SHARDS = 64;           // lists of block-crossing nodes (one counter per 128-byte line, block b appends to list b % 64)
 constexpr int CROSS_STRIDE = 32;           // uint32 words between the shard counters
