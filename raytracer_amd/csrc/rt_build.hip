@@ -6,9 +6,9 @@
 //   k_morton       morton_compute.wgsl:33-69, one thread per triangle
 //   k_onesweep     onesweep LSD radix sort, 3 x 10-bit digits, (key, payload) pairs, STABLE:
 //                  global digit histograms from k_morton, then per digit a single pass with
-//                  chained-scan decoupled look-back, wave64 ballot/popcount ranking (10 ballots per key) and an
+//                  grouped decoupled look-back, wave64 ballot/popcount ranking (10 ballots per key) and an
 //                  LDS-staged scatter
-//   (Karras 2012 radix tree, ties broken by index: inside k_refit_local / k_refit_upper, no kernel or arrays of its own)
+//   (Karras 2012 radix tree, ties broken by index: inside k_refit_local / k_refit_mid, no kernel or arrays of its own)
 //   k_refit_*      one thread per leaf: emit BVH-ordered triangle buffers + leaf record, then climb the nodes inside
 //                  the thread's 256-leaf block through LDS; nodes above the blocks are range queries over leaf boxes
 //                  and sparse tables of block boxes (no hand-off between workgroups inside a launch)
@@ -464,7 +464,7 @@ RT_DEV void karras_children(int n, int i, int j, int gamma, int& c0, int& c1) {
   c1 = (hi == gamma + 1) ? (n - 1) + gamma + 1 : gamma + 1;
 }
 
-// The same node from the same definition, for the nodes whose range crosses a 256-leaf block (k_refit_upper): their ranges
+// The same node from the same definition, for the nodes whose range crosses a 256-leaf block (k_refit_mid): their ranges
 // can be long, and galloping + bisection is a chain of ~3 log2(range) dependent key loads scattered over the key array.
 // delta(i, x) only shrinks as x moves away from i, so any probe sequence that brackets the last position with
 // delta > threshold gives Karras' answer: the search is done by 16 lanes at once (16 probes per round trip: the root's
@@ -596,10 +596,10 @@ __global__ __launch_bounds__(BLK) void k_refit_local(const float* __restrict__ p
   const bool valid = j < n_tri;
   const uint32_t ti = valid ? order[j] : 0u;           // issued here, used after the tree search below
   __syncthreads();
-  if (threadIdx.x == 0) block_key[blockIdx.x] = s_key[1];   // key of position S: the coarse probes of k_refit_upper
+  if (threadIdx.x == 0) block_key[blockIdx.x] = s_key[1];   // key of position S: the coarse probes of k_refit_mid
   // Karras 2012 on the keys in LDS, for internal node i = j.  A probe outside [S, E] is only ever compared with dmin, and a
   // key farther away shares at most as long a prefix as the halo key of that side: if that halo key is still inside the
-  // node's range (delta > dmin) the range crosses the block boundary and the node is left to k_refit_upper; if not, every
+  // node's range (delta > dmin) the range crosses the block boundary and the node is left to k_refit_mid; if not, every
   // probe beyond it fails the comparison too.  Block-local nodes (~96 %) never leave LDS.
   const int first_leaf = n - 1;            // leaf j is node (T-1)+j, one triangle, start = j
   bool is_crossing = false;
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(BLK) void k_refit_local(const float* __restrict__ p
     sb[0] = mn.x; sb[1] = mn.y; sb[2] = mn.z; sb[3] = mx.x; sb[4] = mx.y; sb[5] = mx.z;
   }
   int pe = s_par[threadIdx.x];
-  while (pe >= 0) {                                    // -1: the parent's range leaves the block (k_refit_upper), or this is the root
+  while (pe >= 0) {                                    // -1: the parent's range leaves the block (k_refit_mid), or this is the root
     const int par = pe;
     __threadfence_block();                             // the box is in LDS before the counter moves (one LDS, in-order)
     const uint32_t arrived = atomicAdd(&s_visit[par & (BLK - 1)], 1u);
