@@ -1057,7 +1057,7 @@ int render_frame(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* op
 namespace {
 // A batch of frames of one image shape (rt_render_batch_device): the frames' k_cull / k_compact passes run as the y
 // dimension of two launches and ONE persistent k_render drains all their pixel lists, hottest classes of every frame
-// first - the tail of one frame is filled by the next frame's pixels instead of idling the chip, and the three launches'
+// first - the tail of one frame is filled by the next frame's pixels instead of idling the chip, and the four launches'
 // fixed cost is paid once.  Same per-pixel code as render_frame, hence the same bytes.
 int render_batch(rt_ctx* ctx, uint32_t n_frames, const float* uniforms, const rt_render_opts* opts, void* const* d_rgba8,
                  void* const* d_hit_tri, void* const* d_hit_t) {

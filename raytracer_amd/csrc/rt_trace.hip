@@ -1,8 +1,8 @@
 // rt_trace.hip — hot path 2: per-pixel ray/scene loop of web/compute.wgsl as a persistent-
 // thread, wave64 traversal kernel for gfx950.
 //
-// A frame is three launches: k_cull (pixels whose primary ray misses the root box are final), k_compact (the others go
-// into a pixel list, hottest cost class first) and the persistent k_render: one lane = one list entry, each wave pulls
+// A frame is four launches: k_cull (pixels whose primary ray misses the root box are final), k_scan + k_compact (the others
+// go into a pixel list, hottest cost class first) and the persistent k_render: one lane = one list entry, each wave pulls
 // 64-entry chunks from 64 sharded queue heads (home shard by XCD, then stealing) until the list - one frame's, this
 // rank's stripes', or the lists of a whole batch of frames - is drained.  The traversal stack lives in LDS
 // ([entry][thread], conflict-free) so that dynamic indexing never spills to scratch.
@@ -869,19 +869,67 @@ __global__ __launch_bounds__(TBLK) void k_cull(const RtRenderParams p, const B b
   }
 }
 
+// Phase A1b — scan.  k_cull left one total per block and cost class; one workgroup per frame turns them, in place, into
+// exclusive prefixes over the blocks and writes the frame's list counts: [0] entries, [1] entries of the hottest class,
+// [8 + c] / [16 + c] start / length of class c's run (list order: hottest class first, cheap / unknown (0) last).
+// (k_compact used to fold ALL block totals in EVERY block: 2025 blocks x 32 KB = 65 MB of L2 reads per 4K frame.)
+template <bool BATCH, typename B>
+__global__ __launch_bounds__(TBLK) void k_scan(const RtRenderParams p, const B bt) {
+  const FrameView fv = frame_view<BATCH>(p, bt, BATCH ? blockIdx.x : 0u);
+  __shared__ uint32_t s_wave[TBLK / 64][N_CLASS];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t n_blocks = (p.n_tiles + CULL_TPB - 1) / CULL_TPB;      // = rt_cull_blocks(n_tiles), the grid of k_cull / k_compact
+  const uint32_t per = (n_blocks + TBLK - 1) / TBLK;
+  const uint32_t b0 = min((uint32_t)threadIdx.x * per, n_blocks), b1 = min(b0 + per, n_blocks);   // my consecutive blocks
+  uint32_t sum[N_CLASS];
+#pragma unroll
+  for (int c = 0; c < N_CLASS; ++c) sum[c] = 0u;
+  for (uint32_t b = b0; b < b1; ++b)
+#pragma unroll
+    for (int c = 0; c < N_CLASS; ++c) sum[c] += fv.block_total[(size_t)b * N_CLASS + c];
+  uint32_t run[N_CLASS], tot[N_CLASS];
+#pragma unroll
+  for (int c = 0; c < N_CLASS; ++c) {                     // exclusive scan over the 256 threads: wave scan, then the waves
+    uint32_t inc = sum[c];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) s_wave[w][c] = inc;
+    run[c] = inc - sum[c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < N_CLASS; ++c) {
+    uint32_t before = 0u, all = 0u;
+#pragma unroll
+    for (int i = 0; i < TBLK / 64; ++i) { const uint32_t t = s_wave[i][c]; if (i < w) before += t; all += t; }
+    run[c] += before; tot[c] = all;
+  }
+  for (uint32_t b = b0; b < b1; ++b)
+#pragma unroll
+    for (int c = 0; c < N_CLASS; ++c) {
+      const uint32_t t = fv.block_total[(size_t)b * N_CLASS + c];
+      fv.block_total[(size_t)b * N_CLASS + c] = run[c];
+      run[c] += t;
+    }
+  if (threadIdx.x == 0) {
+    uint32_t above = 0u;
+#pragma unroll
+    for (int c = N_CLASS - 1; c >= 0; --c) { fv.list_count[8 + c] = above; fv.list_count[16 + c] = tot[c]; above += tot[c]; }
+    fv.list_count[0] = above; fv.list_count[1] = tot[N_CLASS - 1];
+  }
+}
+
 // Phase A2 — compact.  Block b owns the same 64 tiles as in k_cull.  List layout: class-major (hot, normal, cheap); inside
 // a class block-major, tile-major, lane order.  Every offset is a sum of k_cull's per-block per-class totals (a few KB
 // read per block) plus a wave scan of the block's 64 tile popcounts: atomic-free and deterministic.
 template <bool BATCH, typename B>
 __global__ __launch_bounds__(TBLK) void k_compact(const RtRenderParams p, const B bt) {
   const FrameView fv = frame_view<BATCH>(p, bt, BATCH ? blockIdx.y : 0u);
-  __shared__ uint32_t s_red[TBLK / 64][2 * N_CLASS];
   __shared__ uint32_t s_pref[N_CLASS][CULL_TPB];
   __shared__ uint32_t s_txy[CULL_TPB];
   __shared__ unsigned long long s_mask[N_CLASS][CULL_TPB];   // the block's masks, read from HBM once (the rounds below took one dependent load each)
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const uint32_t n_blocks = gridDim.x, me = blockIdx.x;
-  uint32_t all[N_CLASS] = {0, 0, 0}, mine[N_CLASS] = {0, 0, 0};     // class totals of the frame / of the blocks before me
+  const uint32_t me = blockIdx.x;
   constexpr int CPW = (N_CLASS + TBLK / 64 - 1) / (TBLK / 64);     // classes per wave: wave w scans classes w, w + 4
   unsigned long long my_mask[CPW];
   {
@@ -892,19 +940,6 @@ __global__ __launch_bounds__(TBLK) void k_compact(const RtRenderParams p, const 
       my_mask[i] = (c < N_CLASS && tile < p.n_tiles) ? fv.masks[(size_t)tile * N_CLASS + c] : 0ull;
     }
     if (w == TBLK / 64 - 1) s_txy[lane] = (tile % p.tiles_x) | ((tile / p.tiles_x) << 16);   // tile coordinates, once per tile
-  }
-  for (uint32_t i = threadIdx.x; i < n_blocks; i += TBLK) {
-#pragma unroll
-    for (int c = 0; c < N_CLASS; ++c) {
-      const uint32_t t = fv.block_total[(size_t)i * N_CLASS + c];
-      all[c] += t;
-      if (i < me) mine[c] += t;
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < N_CLASS; ++c) {
-    const uint32_t a = wave_sum_u32(all[c]), m = wave_sum_u32(mine[c]);
-    if (lane == 0) { s_red[w][c] = a; s_red[w][N_CLASS + c] = m; }
   }
 #pragma unroll
   for (int i = 0; i < CPW; ++i) {                             // a wave scans the block's 64 tile counts of its classes
@@ -921,22 +956,10 @@ __global__ __launch_bounds__(TBLK) void k_compact(const RtRenderParams p, const 
     s_mask[cl][lane] = my_mask[i];
   }
   __syncthreads();
-  uint32_t tot[2 * N_CLASS];
+  // list order: hottest class first, cheap / unknown (0) last; class starts and the prefixes over the blocks are k_scan's
+  uint32_t base[N_CLASS];
 #pragma unroll
-  for (int k = 0; k < 2 * N_CLASS; ++k) {
-    tot[k] = 0;
-#pragma unroll
-    for (int i = 0; i < TBLK / 64; ++i) tot[k] += s_red[i][k];
-  }
-  // list order: hottest class first, cheap / unknown (0) last
-  uint32_t base[N_CLASS], above = 0u;
-#pragma unroll
-  for (int c = N_CLASS - 1; c >= 0; --c) {
-    base[c] = above + tot[N_CLASS + c];
-    if (BATCH && me == 0 && threadIdx.x == 0) { fv.list_count[8 + c] = above; fv.list_count[16 + c] = tot[c]; }   // the class's run in this frame's list
-    above += tot[c];
-  }
-  if (me == 0 && threadIdx.x == 0) { fv.list_count[0] = above; fv.list_count[1] = tot[N_CLASS - 1]; }   // all entries, hottest class
+  for (int c = 0; c < N_CLASS; ++c) base[c] = fv.list_count[8 + c] + fv.block_total[(size_t)me * N_CLASS + c];
   // (a batch shares one set of thresholds and one step histogram: frame 0's block derives them)
   if (me == 0 && w == TBLK / 64 - 1 && p.pix_class && (!BATCH || blockIdx.y == 0)) {   // hot threshold of THIS frame from last frame's step histogram
     // thresholds of classes 2 .. N-1 (list_count[2 ..]): fixed t2 -> one hot class; adaptive -> quantile bands
@@ -1380,6 +1403,7 @@ void rt_launch_render(const RtRenderParams& p_in, int layout, bool count_work, b
   if (p.blocks_per_cu_cap && !getenv("RTCORE_BLOCKS_PER_CU")) p.render_blocks = std::min(p.render_blocks, (uint32_t)n_cu * p.blocks_per_cu_cap);
   RtNoBatch nb;
   hipLaunchKernelGGL((k_cull<false, RtNoBatch>), gc, b, 0, s, p, nb);
+  hipLaunchKernelGGL((k_scan<false, RtNoBatch>), dim3(1), b, 0, s, p, nb);
   hipLaunchKernelGGL((k_compact<false, RtNoBatch>), gc, b, 0, s, p, nb);
   const dim3 g(p.render_blocks);
   const size_t lds = (size_t)p.max_stack * TBLK * (sizeof(uint32_t) + sizeof(float));
@@ -1404,7 +1428,7 @@ void rt_launch_render(const RtRenderParams& p_in, int layout, bool count_work, b
   if (want_stats) hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(256), 0, s, p, split ? 2u * g.x : g.x, p.local_rows * p.width, count_work ? 1 : 0);
 }
 
-// A batch: the frames' cull + compact passes as the y dimension of two launches, then ONE persistent k_render over all
+// A batch: the frames' cull / scan / compact passes as one grid dimension of three launches, then ONE persistent k_render over all
 // the frames' lists (rt_render_batch_device).  p carries what the frames share (tree, geometry of the image, scratch
 // bases); bt what differs.  No stats, no PT split.
 void rt_launch_render_batch(const RtRenderParams& p_in, const RtBatch& bt, int layout, int n_cu, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
@@ -1415,6 +1439,7 @@ void rt_launch_render_batch(const RtRenderParams& p_in, const RtBatch& bt, int l
   p.render_blocks = resident_grid(n_cu, p.max_stack, kernel);
   if (p.blocks_per_cu_cap && !getenv("RTCORE_BLOCKS_PER_CU")) p.render_blocks = std::min(p.render_blocks, (uint32_t)n_cu * p.blocks_per_cu_cap);   // pipelines in flight share the CUs
   hipLaunchKernelGGL((k_cull<true, RtBatch>), gc, b, 0, s, p, batch);
+  hipLaunchKernelGGL((k_scan<true, RtBatch>), dim3(bt.n), b, 0, s, p, batch);
   hipLaunchKernelGGL((k_compact<true, RtBatch>), gc, b, 0, s, p, batch);
   const size_t lds = (size_t)p.max_stack * TBLK * (sizeof(uint32_t) + sizeof(float));
   if (ev0) (void)hipEventRecord(ev0, s);

@@ -1,4 +1,4 @@
-"""rt_render_batch_device (include/rtcore.h): several frames of one image shape through ONE pipeline (one cull launch, one
+"""rt_render_batch_device (include/rtcore.h): several frames of one image shape through ONE pipeline (one cull, one scan and one
 compaction launch, one persistent traversal launch over all the frames' pixel lists).  Every frame of a batch must equal
 the frame rt_render_device gives for the same uniforms bit for bit — image, hit ids, hit distances — whatever the order
 the batch walks the pixels in (hints on / off / converged), for every mode, layout, stripe share and with textures; one
