@@ -65,9 +65,9 @@ def main():
                     help="asynchronous frames in flight per GPU (rtcore.h rt_set_frames_in_flight). auto = 1 on one GPU, so that every "
                          "k_render launch runs alone and its duration is the kernel's own (roofline), 3 with N > 1, where a rank's "
                          "share of the frame is small and mostly tail (3 frame streams + the context stream = the 4 hardware queues)")
-    ap.add_argument("--batch", default="auto", choices=["auto", "1", "2", "3", "4", "5", "6", "7", "8"],
-                    help="frames per pipeline (rtcore.h rt_render_batch_device). auto = 8 (RT_MAX_BATCH): the K steps run as ceil(K / 8) "
-                         "pipelines, each ONE k_render launch over the pixel lists of up to 8 frames (a frame, and even more a rank's "
+    ap.add_argument("--batch", default="auto", choices=["auto"] + [str(k) for k in range(1, 17)],
+                    help="frames per pipeline (rtcore.h rt_render_batch_device). auto = 16 (RT_MAX_BATCH): the K steps run as ceil(K / 16) "
+                         "pipelines of equal size (K = 20: 10 + 10), each ONE k_render launch over the pixel lists of its frames (a frame, and even more a rank's "
                          "stripe share of one, is mostly launch overhead + idle tail on its own: tools/batch_gain.py); with N > 1 one "
                          "exchange per batch on a side stream.  1 = one frame per pipeline (the `per_frame` leg at N = 1)")
     ap.add_argument("--exchange", default="root", choices=["root", "all"],
@@ -154,7 +154,7 @@ def main():
         shade.gi_samples = args.spp
     shade = dict(gi_samples=shade.gi_samples, gi_bounces=shade.gi_bounces, soft_samples=shade.soft_samples, max_stack=shade.max_stack)
     base = rt.render_opts(mode=mode, layout=layout, flags=tflag, **shade)
-    batch = (1 if frag else 8) if args.batch == "auto" else int(args.batch)     # the older fragment shaders run one frame per pipeline
+    batch = (1 if frag else 16) if args.batch == "auto" else int(args.batch)     # the older fragment shaders run one frame per pipeline
     if frag and batch > 1:
         raise SystemExit("--batch > 1 renders through rt_render_batch_device: --mode primary|shadow|pt only")
     # pipelines (frames, or batches of frames) in flight: 1 at N = 1, so that every k_render launch runs alone and its duration is
@@ -170,8 +170,9 @@ def main():
             for i in range(n):
                 frame.step(views[i % len(views)], want_stats=False)
             return
-        for i0 in range(0, n, batch):
-            bframes.step(np.stack([views[i % len(views)] for i in range(i0, min(i0 + batch, n))]))
+        size = -(-n // -(-n // batch)) if n > 0 else 0          # ceil(n / batches), batches = ceil(n / batch): pipelines of equal size
+        for i0 in range(0, n, max(size, 1)):
+            bframes.step(np.stack([views[i % len(views)] for i in range(i0, min(i0 + size, n))]))
 
     # one counted launch (untimed): rays + work counters of this rank's share of the frame
     copts = rt.render_opts(mode=mode, layout=layout, flags=rt.FLAG_COUNT_WORK | tflag, **shade,
@@ -221,7 +222,10 @@ def main():
         b2 = rdist.GpuBackend(ctx, device, frames_in_flight=2)
         if batch > 1:                   # two BATCHES in flight: cull / compaction and the head of batch i+1 beside the tail of batch i
             frame2 = rdist.BatchedFrames(b2, W, H, rank, world, batch, base)
-            go = lambda n: [frame2.step(np.stack([U] * min(batch, n - i0))) for i0 in range(0, n, batch)]
+            def go(n):
+                size = -(-n // -(-n // batch)) if n > 0 else 1
+                for i0 in range(0, n, max(size, 1)):
+                    frame2.step(np.stack([U] * min(size, n - i0)))
             go(2 * batch)               # both frame slots size their scratch
         else:
             frame2 = rdist.ShardedFrame(b2, W, H, rank, world, base)
@@ -362,7 +366,7 @@ def pmc_traffic(args, world, textured, batch, frames_per_launch):
         return {}
     if int(w.get("frames_per_pipeline", 1)) != batch:
         return {}
-    # counters are per launch of the collection run; this run's launches may hold another number of frames (K = 20 -> 8 + 8 + 4)
+    # counters are per launch of the collection run; this run's launches may hold another number of frames (K = 20 -> 10 + 10)
     per_frame = t.get("k_render_hbm_bytes_per_launch", 0) / max(float(t.get("frames_per_launch", 1.0)), 1e-9)
     return {"k_render_hbm_bytes_per_launch": int(per_frame * frames_per_launch), "k_render_valu_lane_util": t.get("k_render_valu_lane_util"),
             "source": "profiles/traffic.json: " + str(t.get("source", ""))}

@@ -1079,7 +1079,7 @@ int render_batch(rt_ctx* ctx, uint32_t n_frames, const float* uniforms, const rt
     void* o[3] = {d_rgba8 ? d_rgba8[f] : nullptr, d_hit_tri ? d_hit_tri[f] : nullptr, d_hit_t ? d_hit_t[f] : nullptr};
     if (((reinterpret_cast<uintptr_t>(o[0]) | reinterpret_cast<uintptr_t>(o[1]) | reinterpret_cast<uintptr_t>(o[2])) & 3u) != 0u)
       return ctx->fail(RT_ERR_INVALID, "output pointers must be 4-byte aligned");
-    std::memcpy(bt.U[f], U, sizeof(float) * 44);
+    std::memcpy(bt.U[f], U, sizeof(float) * RT_U_FLOATS);
     bt.rgba8[f] = static_cast<uint8_t*>(o[0]); bt.hit_tri[f] = static_cast<uint32_t*>(o[1]); bt.hit_t[f] = static_cast<float*>(o[2]);
   }
   DeviceGuard g(ctx->device);
@@ -1154,7 +1154,7 @@ int render_batch(rt_ctx* ctx, uint32_t n_frames, const float* uniforms, const rt
   }
   for (uint32_t f = 0; f < n_frames; ++f) {
     RtRenderParams pf = p;
-    std::memcpy(pf.U, bt.U[f], sizeof(float) * 44);
+    std::memcpy(pf.U, uniforms + 44 * (size_t)f, sizeof(float) * 44);
     rt_cull_rect(pf, ctx->bvh.root_box);
     bt.cull[f][0] = pf.cull_x0; bt.cull[f][1] = pf.cull_x1; bt.cull[f][2] = pf.cull_y0; bt.cull[f][3] = pf.cull_y1;
   }

@@ -97,13 +97,14 @@ struct RtRenderParams {
 // Several frames of one shape in one frame pipeline (rt_render_batch_device): k_cull / k_compact run with the frame as
 // grid.y over per-frame scratch regions, ONE persistent k_render walks all the frames' pixel lists, hottest class of every
 // frame first.  Passed by value next to RtRenderParams (whose U / outputs / cull rectangle are then unused).
+constexpr int RT_U_FLOATS = 40;
 struct RtBatch {
   uint32_t n;
   uint32_t mask_stride;      // u64 words between the frames' tile-mask arrays
   uint32_t bt_stride;        // u32 words between the frames' block totals
   uint32_t list_stride;      // u32 words between the frames' pixel lists
   uint32_t lc_stride;        // u32 words between the frames' list_count blocks
-  float     U[RT_MAX_BATCH][44];
+  float     U[RT_MAX_BATCH][RT_U_FLOATS];   // the uniform floats the kernels read: 0 .. 38 (compute.wgsl:4-13), padded to 40
   uint8_t*  rgba8[RT_MAX_BATCH];
   uint32_t* hit_tri[RT_MAX_BATCH];
   float*    hit_t[RT_MAX_BATCH];

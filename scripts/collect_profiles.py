@@ -26,14 +26,14 @@ allk = json.load(open(os.path.join(src, "traffic_all.json")))
 main = [k for k in allk if k.startswith("k_render<0, false, true, 0, true")]      # WIDE64, no counters, textured, pixel kind, batch
 assert len(main) == 1, list(allk)
 ks_bench = json.loads(open(os.path.join(src, "ks", "bench.json")).read().strip().splitlines()[-1])
-# launches of the batch kernel in one pass of `--steps 20 --warmup 5`: set-up batch (8 frames), warm-up (5), timed (8 + 8 + 4)
-FRAMES_PER_LAUNCH = (8 + 5 + 8 + 8 + 4) / 5.0
+# launches of the batch kernel in one pass of `--steps 20 --warmup 5`: set-up batch (16 frames), warm-up (5), timed (10 + 10)
+FRAMES_PER_LAUNCH = (16 + 5 + 10 + 10) / 4.0
 t = {"workload": {"scene": "s1m", "width": 3840, "height": 2160, "mode": "shadow", "layout": "wide64", "spp": 32, "textured": True,
-                  "frames_per_pipeline": 8},
+                  "frames_per_pipeline": 16},
      "frames_per_launch": FRAMES_PER_LAUNCH,
      "source": f"profiles/{RND}/pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE and lane passes of `python3 bench.py --no-cpu-baseline "
                "--no-fif2 --no-legs --steps 20 --warmup 5`, scripts/pmc_passes.sh; per LAUNCH of the batch kernel, a launch holding "
-               f"{FRAMES_PER_LAUNCH} frames on average: set-up 8, warm-up 5, timed 8 + 8 + 4)",
+               f"{FRAMES_PER_LAUNCH} frames on average: set-up 16, warm-up 5, timed 10 + 10)",
      "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md, HBM/rocprofv3: gfx950 FETCH_SIZE reports half of the "
                    "bytes read; Infinity-Cache hits are counted, so this is fabric-side traffic, an upper bound on HBM bytes)",
      "k_render_fetch_size_kb_raw": allk[main[0]]["fetch_size_kb_raw"], "k_render_write_size_kb_raw": allk[main[0]]["write_size_kb_raw"],
@@ -48,7 +48,7 @@ print("bench_n1:", b["value"], b["unit"], b["ms_per_step"], "ms; roofline", b["r
 # build: kernel trace + stage times, and the fabric traffic of the build kernels (same PMC passes: bench.py builds 5 times)
 for f in ("build_kernel_stats.csv", "build.txt"):
     shutil.copy(os.path.join(src, "build", f), os.path.join(dst, f))
-for f in ("build_nosurface.txt", "build_cfg5.txt", "batch_gain.txt", "batch_gain_moving.txt", "project_scaling_batch8.txt", "project_scaling_per_frame.txt"):
+for f in ("build_nosurface.txt", "build_cfg5.txt", "batch_gain.txt", "batch_gain_moving.txt", "project_scaling_batch16.txt", "project_scaling_per_frame.txt"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 build_kernels = [k for k in allk if k.split("<")[0] in ("k_bounds", "k_bounds_final", "k_morton", "k_onesweep", "k_refit_local", "k_refit_mid", "k_refit_spans")]

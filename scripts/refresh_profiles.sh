@@ -24,6 +24,6 @@ timeout -k 10 120 python -u tools/build_only.py s1m 30 nosurface > "$O/build_nos
 timeout -k 10 300 python -u tools/build_only.py lattice76 6 nosurface > "$O/build_cfg5.txt" 2>&1
 echo "[9] batches, scaling projection"; timeout -k 10 300 python -u tools/batch_gain.py > "$O/batch_gain.txt" 2>&1
 timeout -k 10 300 python -u tools/batch_gain.py --moving > "$O/batch_gain_moving.txt" 2>&1
-PROJ_BATCH=8 timeout -k 10 300 python -u tools/project_scaling.py > "$O/project_scaling_batch8.txt" 2>&1
+PROJ_BATCH=16 timeout -k 10 300 python -u tools/project_scaling.py > "$O/project_scaling_batch16.txt" 2>&1
 PROJ_BATCH=1 timeout -k 10 300 python -u tools/project_scaling.py > "$O/project_scaling_per_frame.txt" 2>&1
 echo done

@@ -72,7 +72,7 @@ static void die(const char* what, rt_ctx* ctx, int rc) {
 struct Options {
   std::string obj, mtl_dir, out_path, save_bvh, load_bvh;
   uint32_t width = 1920, height = 1080;
-  int device = 0, frames = 1, gpus = 0, batch = 8;
+  int device = 0, frames = 1, gpus = 0, batch = RT_MAX_BATCH;
   bool quad = false, textured = false, v2 = false;
   std::vector<std::pair<int, std::string>> tex_files;
   rt_render_opts opts;

@@ -68,7 +68,7 @@ def run(n_cases, seed0, log=print):
     stack = int(rng.choice([2, 3, 5, 12, 32]))
     w, h = int(rng.integers(8, 120)), int(rng.integers(8, 90))
     gi, nb, soft = int(rng.integers(1, 5)), int(rng.integers(0, 4)), int(rng.integers(1, 6))
-    n_frames = int(rng.integers(1, 9))
+    n_frames = int(rng.integers(1, 17))
     world = int(rng.choice([1, 1, 2, 3]))
     rank = int(rng.integers(0, world))
     params = dict(case=case, seed=seed0 + case, kind=kind, T=T, enc=enc, mode=mode, layout=layout, stack=stack, w=w, h=h, gi=gi, nb=nb,

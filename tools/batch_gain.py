@@ -29,7 +29,7 @@ def case(name, mesh, W, H, stripe=None, stripe_rows=16):
     oc = rt.render_opts(mode=rt.MODE_SHADOW, flags=rt.FLAG_TEXTURED | rt.FLAG_COUNT_WORK, **so)
     rows = rt.packed_rows(H, stripe_rows, *stripe) if stripe else H
     views = [rt.make_uniforms(W, H, cam_pos=(0.0, 0.0, 1.3), rot_deg=(0.0, (1.0 * k if moving else 0.0), 0.0)) for k in range(8)]
-    bufs = torch.empty((8, rows, W), dtype=torch.int32, device=dev)
+    bufs = torch.empty((16, rows, W), dtype=torch.int32, device=dev)
     c = ctx.render_device(views[0], oc, d_rgba8=bufs[0].data_ptr())
     byts = 32 * c["box_tests"] + 48 * c["tri_tests"] + 48 * c["hit_updates"] + 4 * c["pixels"] - 36 * (c["pixels"] - c["pixels_traced"])
     n = 240
@@ -52,11 +52,11 @@ def case(name, mesh, W, H, stripe=None, stripe_rows=16):
         e = time.perf_counter() - t0
         _, tr, k = ctx.profile_end()
         report(f"per frame, {fif} in flight", e, tr, k)
-    for fif, sizes in ((1, (2, 4, 8)), (2, (4, 8)), (3, (8,))):
+    for fif, sizes in ((1, (2, 4, 8, 16)), (2, (8, 16))):
       ctx.set_frames_in_flight(fif)
       for B in sizes:
           ptrs = [bufs[f].data_ptr() for f in range(B)]
-          Ub = [np.stack([views[(i0 + f) % 8] for f in range(B)]) for i0 in range(0, 8, B)]
+          Ub = [np.stack([views[(i0 + f) % 8] for f in range(B)]) for i0 in range(0, max(8, B), B)]
           for i in range(4):
               ctx.render_batch_device(Ub[i % len(Ub)], o, ptrs)
           (ctx.frames_join(0), ctx.synchronize())

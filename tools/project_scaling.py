@@ -93,7 +93,7 @@ def run(world, rank, fif, n=200):
 
 
 order = (lambda w: range(w)) if "--reverse" not in sys.argv else (lambda w: reversed(range(w)))
-BATCH = int(os.environ.get("PROJ_BATCH", "8"))       # frames per pipeline, as bench.py --batch; 1: one frame per pipeline with PROJ_FIF frames in flight (the round-1 loop)
+BATCH = int(os.environ.get("PROJ_BATCH", "16"))       # frames per pipeline, as bench.py --batch; 1: one frame per pipeline with PROJ_FIF frames in flight (the round-1 loop)
 t1 = run_batched(1, 0, BATCH) if BATCH > 1 else run(1, 0, 1)
 print(f"N=1 ({BATCH} frames per pipeline, as bench.py): {t1:.4f} ms/frame" if BATCH > 1 else f"N=1 (one frame per pipeline, one in flight): {t1:.4f} ms/frame", flush=True)
 worlds = (2, 4, 8) if "--worlds" not in sys.argv else tuple(int(v) for v in sys.argv[sys.argv.index("--worlds") + 1].split(","))
