@@ -170,9 +170,10 @@ def main():
             for i in range(n):
                 frame.step(views[i % len(views)], want_stats=False)
             return
-        size = -(-n // -(-n // batch)) if n > 0 else 0          # ceil(n / batches), batches = ceil(n / batch): pipelines of equal size
-        for i0 in range(0, n, max(size, 1)):
-            bframes.step(np.stack([views[i % len(views)] for i in range(i0, min(i0 + size, n))]))
+        i0 = 0
+        for size in rdist.batch_sizes(n, batch):             # pipelines of equal size (K = 20, 16 at most per pipeline: 10 + 10)
+            bframes.step(np.stack([views[i % len(views)] for i in range(i0, i0 + size)]))
+            i0 += size
 
     # one counted launch (untimed): rays + work counters of this rank's share of the frame
     copts = rt.render_opts(mode=mode, layout=layout, flags=rt.FLAG_COUNT_WORK | tflag, **shade,
@@ -222,10 +223,7 @@ def main():
         b2 = rdist.GpuBackend(ctx, device, frames_in_flight=2)
         if batch > 1:                   # two BATCHES in flight: cull / compaction and the head of batch i+1 beside the tail of batch i
             frame2 = rdist.BatchedFrames(b2, W, H, rank, world, batch, base)
-            def go(n):
-                size = -(-n // -(-n // batch)) if n > 0 else 1
-                for i0 in range(0, n, max(size, 1)):
-                    frame2.step(np.stack([U] * min(size, n - i0)))
+            go = lambda n: [frame2.step(np.stack([U] * size)) for size in rdist.batch_sizes(n, batch)]
             go(2 * batch)               # both frame slots size their scratch
         else:
             frame2 = rdist.ShardedFrame(b2, W, H, rank, world, base)

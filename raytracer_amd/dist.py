@@ -239,6 +239,15 @@ class ShardedFrame:
             self.b.finish()
 
 
+def batch_sizes(n, batch):
+    """n frames as ceil(n / batch) pipelines of (nearly) equal size: 20 frames, 16 per pipeline at most -> [10, 10]."""
+    if n <= 0:
+        return []
+    k = -(-n // batch)
+    q, r = divmod(n, k)
+    return [q + 1] * r + [q] * (k - r)
+
+
 class BatchedFrames:
     """B frames of one image shape per step: this rank's stripes of all B frames are rendered by ONE pipeline
     (rt_render_batch_device: the launches' fixed cost and the idle tail of a small stripe share are paid once per batch,

@@ -166,6 +166,16 @@ def test_world2_gloo_sharded_frame():
     assert res == [(0, True), (1, True)]
 
 
+def test_batch_sizes_are_even():
+    from raytracer_amd import dist as rdist
+    assert rdist.batch_sizes(20, 16) == [10, 10] and rdist.batch_sizes(20, 8) == [7, 7, 6] and rdist.batch_sizes(5, 16) == [5]
+    assert rdist.batch_sizes(16, 16) == [16] and rdist.batch_sizes(17, 16) == [9, 8] and rdist.batch_sizes(0, 16) == []
+    for n in range(1, 70):
+        for b in (1, 3, 8, 16):
+            sz = rdist.batch_sizes(n, b)
+            assert sum(sz) == n and max(sz) <= b and max(sz) - min(sz) <= 1 and len(sz) == -(-n // b)
+
+
 def test_stripe_ownership_partition():
     from raytracer_amd import dist as rdist
     for h in (1, 16, 33, 150, 2160):
