@@ -73,6 +73,10 @@ def main():
     ap.add_argument("--exchange", default="root", choices=["root", "all"],
                     help="N > 1: where the frame's stripes are gathered — root = rank 0 only (the viewer's rank: grouped send/recv, each "
                          "byte crosses one xGMI link once), all = every rank (all_gather, N times the traffic)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 on a ONE-GPU box: every rank uses cuda:0 and the collectives run over gloo, staged through host memory (RCCL "
+                         "refuses two ranks on one device).  Exercises the whole N > 1 code path (replication, stripes, batched exchange, "
+                         "de-interleave, reductions); its numbers mean nothing and the line says so")
     ap.add_argument("--no-fif2", action="store_true", help="skip the extra two-frames-in-flight loop at N = 1")
     ap.add_argument("--no-legs", action="store_true", help="skip the unhinted and moving-camera legs at N = 1")
     ap.add_argument("--no-texture", action="store_true",
@@ -96,8 +100,12 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if args.rehearse_on_one_gpu:
+            local = 0
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     device = torch.device(f"cuda:{local}")
     torch.cuda.set_device(device)
 
@@ -216,6 +224,16 @@ def main():
     kernel_ms, trav_ms, n_launch = ctx.profile_end()   # frame pipeline (cull, compact, traversal, stats) / k_render alone, per launch
     frames_per_launch = args.steps / max(n_launch, 1)  # 1, or the mean batch size (a k_render launch then walks that many frames' lists)
 
+    # N > 1: the frame rank 0 assembled from all ranks' stripes (the last timed one) against rank 0's own render of the whole
+    # frame — outside the timed region; says on the driver's 8-GPU run that the exchange delivered the right pixels
+    frame_check = None
+    if world > 1 and rank == 0:
+        assembled = bframes.images[0] if bframes is not None else frame.image
+        whole = torch.zeros((H, W), dtype=torch.int32, device=device)
+        ctx.render_device(U, base, d_rgba8=whole.data_ptr(), want_stats=False)
+        ctx.synchronize()
+        frame_check = "identical" if torch.equal(whole, assembled) else f"{int((whole != assembled).sum())} pixels differ"
+
     # the same K frames again with two frames in flight (only where the main loop ran with one): whole-job throughput when
     # the tail of one frame may overlap the head of the next; reported beside `value`, never as `value` at N = 1
     fif2 = None
@@ -278,7 +296,8 @@ def main():
         run_frames([U], 3 * batch)      # leave the context as the main loop had it: hints of the static view
         fence()
 
-    tot = torch.tensor([float(my_rays), float(my_bytes), elapsed, kernel_ms, float(my_rays_traced)], dtype=torch.float64, device=device)
+    tot = torch.tensor([float(my_rays), float(my_bytes), elapsed, kernel_ms, float(my_rays_traced)], dtype=torch.float64,
+                       device="cpu" if args.rehearse_on_one_gpu else device)     # (gloo rehearsal: reductions on host tensors)
     if world > 1:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -333,6 +352,10 @@ def main():
                                          if pmc.get("k_render_hbm_bytes_per_launch") and trav_ms > 0 else None),
                          "valu_lane_util": pmc.get("k_render_valu_lane_util")},
         }
+        if frame_check is not None:
+            out["assembled_frame_vs_single_gpu_render"] = frame_check
+        if args.rehearse_on_one_gpu and world > 1:
+            out["rehearsal"] = f"{world} ranks sharing cuda:0, collectives over gloo: exercises the N > 1 code path, NOT a measurement"
         if legs:
             out["legs"] = legs
         if fif2 is not None:

@@ -113,10 +113,32 @@ class GpuBackend:
         return ev
 
 
+def _through_host(t):
+    """gloo groups (rehearsals of the N > 1 path with several ranks on ONE GPU, where RCCL refuses to run) move device tensors
+    through host memory: torch's gloo backend accepts device tensors but hung now and then on an idle device here (all ranks
+    inside the same all_gather).  RCCL groups never take this path."""
+    return t is not None and t.is_cuda and dist.get_backend() == "gloo"
+
+
+def all_gather_into(out, chunk):
+    if _through_host(chunk):
+        h = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(h, chunk.cpu())
+        out.copy_(h)
+    else:
+        dist.all_gather_into_tensor(out, chunk)
+
+
 def gather_stripes(gathered, packed, root_only):
     """The frame's one exchange step.  gathered: [world * rows_per_rank, width] (rank-major), or None off the root."""
     if not root_only:
-        dist.all_gather_into_tensor(gathered, packed)
+        all_gather_into(gathered, packed)
+    elif _through_host(packed):
+        world = dist.get_world_size()
+        h = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype) if dist.get_rank() == 0 else None
+        dist.gather(packed.cpu(), list(h.unbind(0)) if h is not None else None, dst=0)
+        if h is not None:
+            gathered.view(h.shape).copy_(h)
     elif dist.get_rank() == 0:
         dist.gather(packed, list(gathered.view(dist.get_world_size(), *packed.shape).unbind(0)), dst=0)
     else:
@@ -135,7 +157,12 @@ def replicate_bvh(ctx, rank, world, device):
         T, N = ctx.counts()
         uv_ptr, uv_bytes = ctx.tri_uv_device() if hasattr(ctx, "tri_uv_device") else (0, 0)
         meta[0], meta[1], meta[2], meta[3] = T, N, ctx.node_encoding(), 1 if uv_bytes else 0
-    dist.broadcast(meta, 0)
+    if _through_host(meta):
+        h = meta.cpu()
+        dist.broadcast(h, 0)
+        meta.copy_(h)
+    else:
+        dist.broadcast(meta, 0)
     T, N, enc, has_uv = int(meta[0]), int(meta[1]), int(meta[2]), int(meta[3])
     seg = [32 * N, 48 * T, 48 * T] + ([32 * T] if has_uv else [])      # bytes; every offset is a multiple of 16
     off = [0]
@@ -153,8 +180,13 @@ def replicate_bvh(ctx, rank, world, device):
             ctx.synchronize()           # the exports ran on the context stream; the collectives below run on torch's
     if world > 1:
         chunk = torch.empty(total // world, dtype=torch.uint8, device=device)
-        dist.scatter(chunk, list(blob.view(world, -1).unbind(0)) if rank == 0 else None, src=0)
-        dist.all_gather_into_tensor(blob, chunk)        # (rank 0 receives what it already holds)
+        if _through_host(chunk):
+            h = torch.empty(total // world, dtype=torch.uint8)
+            dist.scatter(h, list(blob.cpu().view(world, -1).unbind(0)) if rank == 0 else None, src=0)
+            chunk.copy_(h)
+        else:
+            dist.scatter(chunk, list(blob.view(world, -1).unbind(0)) if rank == 0 else None, src=0)
+        all_gather_into(blob, chunk)                    # (rank 0 receives what it already holds)
         del chunk
     if torch.device(device).type == "cuda":
         torch.cuda.synchronize(device)
