@@ -33,6 +33,9 @@ constexpr int SORT_TILE = BLK * SORT_KPT;          // 5120 keys per tile
 constexpr uint32_t ST_AGG = 1u << 30, ST_INCL = 2u << 30, ST_MASK = (1u << 30) - 1u;
 constexpr uint32_t SPIN_LIMIT = 1u << 24;          // bounded look-back spin (error flag instead of a hang)
 
+// look-back words of one sort pass: n_tiles rows of 2 KB (u16 per digit), then, 4 KB-aligned, one 4 KB row (u32 per digit) per group
+__host__ __device__ inline uint32_t sort_group_rows_offset(uint32_t n_tiles) { return (n_tiles * (uint32_t)(RADIX * 2) + 4095u) & ~4095u; }
+
 inline int grid_for(uint32_t n, int per_block, int cap = 2048) {
   long g = ((long)n + per_block - 1) / per_block;
   if (g < 1) g = 1;
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(BLK, 2)    // 2 blocks per CU (60 KB of LDS each): 
 void k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                   uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                   uint32_t n, int shift, const uint32_t* __restrict__ hist,
-                                                  uint32_t* status /* [n_tiles + groups][RADIX] */, uint32_t n_tiles, uint32_t status_bytes,
+                                                  uint32_t* status /* n_tiles rows of u16[RADIX], then (4 KB-aligned) one row of u32[RADIX] per group */, uint32_t n_tiles, uint32_t status_bytes,
                                                   int gshift, int use_ticket, uint32_t* tile_counter, uint32_t* err_flag) {
   __shared__ uint32_t s_keys[SORT_TILE];
   __shared__ uint32_t s_vals[SORT_TILE];
@@ -225,7 +228,9 @@ void k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
   for (int i = tid; i < (BLK / 64) * RADIX / 4; i += BLK) reinterpret_cast<uint4*>(&s_whist[0][0])[i] = make_uint4(0u, 0u, 0u, 0u);
   reinterpret_cast<uint4*>(s_cnt)[tid] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
-  const uint32_t tile = use_ticket ? s_tile : blockIdx.x;
+  // (wave-uniform by construction; said so explicitly: everything derived from it - row addresses, the number of look-back
+  // words to fetch - then lives in scalar registers, and rows that do not exist are skipped by a branch instead of predicated)
+  const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)(use_ticket ? s_tile : blockIdx.x));
   const uint32_t base = tile * (uint32_t)SORT_TILE;
   const uint32_t wbase = base + (uint32_t)wave * (64 * SORT_KPT);
   SORT_STAMP(0);
@@ -255,41 +260,71 @@ void k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
     const uint4 c = reinterpret_cast<const uint4*>(s_cnt)[tid];    // thread t owns digits 4t .. 4t+3
     total[0] = c.x; total[1] = c.y; total[2] = c.z; total[3] = c.w;
   }
-  // Look-back words: one u32 per digit = 2-bit flag | 30-bit count, self-validating (a torn 16-byte access is harmless: every
-  // word carries its own flag).  A thread's four digits travel as ONE 16-byte write-through (sc1) store and are read with
-  // 16-byte sc1 loads (half the fabric writes of 8-byte words: the small write-through stores are what the pass waits for).
+  // Look-back words, self-validating (a torn access is harmless: every word carries its own flag), moved with write-through
+  // (sc1) buffer stores and sc1 loads:
+  //   GROUP rows (4 KB each, behind the tile rows): one u32 per digit = 2-bit flag | 30-bit count; a thread's four digits
+  //     travel as ONE 16-byte access;
+  //   TILE rows (2 KB each): one u16 per digit = bit 15 "there" | the tile's count (<= SORT_TILE < 2^15); a thread's four
+  //     digits are ONE 8-byte access, so all of a group's <= 31 predecessors fit the registers of a single round trip.
+  static_assert(SORT_TILE < (1 << 15), "tile words are 16 bits");
   const __amdgpu_buffer_rsrc_t st_rsrc = __builtin_amdgcn_make_buffer_rsrc(status, 0, (int)status_bytes, 0x00020000);
-  const uint32_t my_off = 16u * (uint32_t)tid;              // byte offset of my four words inside a tile's / group's 4 KB row
-  auto publish = [&](uint32_t row, uint32_t f, const uint32_t v[DPT]) {
+  const uint32_t my_off = 16u * (uint32_t)tid;              // byte offset of my four words inside a group's 4 KB row
+  const uint32_t group_rows = sort_group_rows_offset(n_tiles);
+  auto publish = [&](uint32_t g, uint32_t f, const uint32_t v[DPT]) {
     const u32x4 x = {f | v[0], f | v[1], f | v[2], f | v[3]};
-    __builtin_amdgcn_raw_buffer_store_b128(x, st_rsrc, row * (uint32_t)(RADIX * 4) + my_off, 0, 16);      // aux 16 = sc1
+    __builtin_amdgcn_raw_buffer_store_b128(x, st_rsrc, my_off, group_rows + g * (uint32_t)(RADIX * 4), 16);      // aux 16 = sc1
   };
-  auto fetch = [&](uint32_t row) -> uint4 {
-    const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(st_rsrc, row * (uint32_t)(RADIX * 4) + my_off, 0, 16);
+  auto fetch = [&](uint32_t g) -> uint4 {
+    const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(st_rsrc, my_off, group_rows + g * (uint32_t)(RADIX * 4), 16);   // (row: scalar offset)
     return make_uint4(x[0], x[1], x[2], x[3]);
   };
-  publish(tile, ST_AGG, total);
-  constexpr int LBG = 16;                                  // predecessors of my group fetched per round trip
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  auto fetch_tile = [&](uint32_t t) -> uint2 {
+    const u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(st_rsrc, 8u * (uint32_t)tid, t * (uint32_t)(RADIX * 2), 16);
+    return make_uint2(x[0], x[1]);
+  };
+  {
+    const u32x2 x = {0x80008000u | total[0] | (total[1] << 16), 0x80008000u | total[2] | (total[3] << 16)};
+    __builtin_amdgcn_raw_buffer_store_b64(x, st_rsrc, 8u * (uint32_t)tid, tile * (uint32_t)(RADIX * 2), 16);
+  }
+  constexpr int LBG = 32;                                  // predecessors of my group fetched per round trip (a whole group of 32)
   constexpr int LB = 16;                                   // group words fetched per round trip
   const uint32_t grp = tile >> gshift, g0 = grp << gshift;
   const bool closes_group = ((tile + 1u) & ((1u << gshift) - 1u)) == 0u;
   uint32_t excl[DPT] = {0u, 0u, 0u, 0u};
   uint32_t spins = 0;
   bool fail = false;
-  auto in_group_sum = [&]() {                              // counts of the predecessors p-1 .. g0 of my group: pure sums, any order
+  // (the nearest group words are fetched in the same round trip as the in-group words when `with_groups`: the walk below
+  // starts from them)
+  constexpr int PG = 8;
+  uint4 pre_g[PG];
+  bool have_pre_g = false;
+  auto in_group_sum = [&](bool with_groups) {                              // counts of the predecessors p-1 .. g0 of my group: pure sums, any order
     for (uint32_t p = tile; p > g0 && !fail;) {
       const uint32_t nb = (p - g0 < (uint32_t)LBG) ? (p - g0) : (uint32_t)LBG;
       for (;;) {                                           // the whole batch again if any word is not there yet (never a stale register copy)
-        uint4 w[LBG];
+        uint2 w[LBG];
 #pragma unroll
-        for (int k = 0; k < LBG; ++k) if ((uint32_t)k < nb) w[k] = fetch(p - 1u - k);
-        uint32_t ready = 3u << 30;
+        for (int k = 0; k < LBG; ++k) if ((uint32_t)k < nb) w[k] = fetch_tile(p - 1u - k);
+        if (with_groups && !have_pre_g && grp > 0u) {
 #pragma unroll
-        for (int k = 0; k < LBG; ++k) if ((uint32_t)k < nb) ready = min(ready, min(min(w[k].x >> 30, w[k].y >> 30), min(w[k].z >> 30, w[k].w >> 30)));
-        if (ready != 0u) {
+          for (int k = 0; k < PG; ++k) if ((uint32_t)k < grp) pre_g[k] = fetch(grp - 1u - k);
+          have_pre_g = true;
+        }
+        uint32_t all = ~0u;                                // all there <=> every half-word has its bit 15
 #pragma unroll
-          for (int k = 0; k < LBG; ++k)
-            if ((uint32_t)k < nb) { excl[0] += w[k].x & ST_MASK; excl[1] += w[k].y & ST_MASK; excl[2] += w[k].z & ST_MASK; excl[3] += w[k].w & ST_MASK; }
+        for (int k = 0; k < LBG; ++k) if ((uint32_t)k < nb) all &= w[k].x & w[k].y;
+        if ((all & 0x80008000u) == 0x80008000u) {
+          // four words are added as packed halves (4 x SORT_TILE < 2^16), then unpacked
+#pragma unroll
+          for (int c = 0; c < LBG; c += 4) {
+            if ((uint32_t)c < nb) {
+              uint32_t a = 0u, b = 0u;
+#pragma unroll
+              for (int k = c; k < c + 4; ++k) if ((uint32_t)k < nb) { a += w[k].x & 0x7FFF7FFFu; b += w[k].y & 0x7FFF7FFFu; }
+              excl[0] += a & 0xFFFFu; excl[1] += a >> 16; excl[2] += b & 0xFFFFu; excl[3] += b >> 16;
+            }
+          }
           break;
         }
         if (++spins > SPIN_LIMIT) { atomicOr(err_flag, 1u); fail = true; break; }
@@ -302,9 +337,9 @@ void k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
   // of their own run) and publishes the group's sum before it ranks: by the time the other tiles have ranked their keys,
   // every group word they need is there.  Group 0's sum is already its inclusive prefix.
   if (closes_group) {
-    in_group_sum();
+    in_group_sum(false);
     const uint32_t v[DPT] = {excl[0] + total[0], excl[1] + total[1], excl[2] + total[2], excl[3] + total[3]};
-    publish(n_tiles + grp, grp == 0u ? ST_INCL : ST_AGG, v);
+    publish(grp, grp == 0u ? ST_INCL : ST_AGG, v);
   }
   SORT_STAMP(1);
   // 2. wave-level stable ranking: peers = lanes holding the same digit (10 ballots), rank inside
@@ -321,13 +356,13 @@ void k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
       const unsigned long long bal = __ballot(bit);
       peers &= bit ? bal : ~bal;
     }
-    int leader = lane;
+    // the wave's counter of digit d so far, read by every peer, then bumped by the group's first lane: LDS operations of one
+    // wave execute in order and s_whist[wave] is this wave's own (no returning atomic + lane shuffle: one LDS round trip less)
     uint32_t prev = 0;
     if (valid) {
-      leader = __ffsll((long long)peers) - 1;
-      if (lane == leader) prev = atomicAdd(&s_whist[wave][d], (uint32_t)__popcll(peers));
+      prev = s_whist[wave][d];
+      if (lane == __ffsll((long long)peers) - 1) atomicAdd(&s_whist[wave][d], (uint32_t)__popcll(peers));
     }
-    prev = (uint32_t)__shfl((int)prev, leader);
     rank[r] = prev + (uint32_t)__popcll(peers & lt_mask);
   }
   __syncthreads();
@@ -346,63 +381,25 @@ void k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
   //   1. every tile publishes its counts (AGG) before it ranks (above);
   //   2. the last tile of a group sums its group's counts and publishes the group's sum (AGG; group 0: INCL) in a second
   //      array, also before it ranks (above);
-  //   3. after ranking, every tile sums the counts of the predecessors INSIDE its group (all fetched at once) and walks back
-  //      over the GROUP words (16 per round trip, in order, until an INCL);
+  //   3. after ranking (and after the tile-local scatter into LDS), every tile sums the counts of the predecessors INSIDE
+  //      its group and walks back over the GROUP words (in order, until an INCL): the <= 31 tile words and the nearest 8 group
+  //      words in one round trip, further group words 16 per round trip;
   //   4. the last tile of a group then publishes the group's inclusive prefix (INCL).
   // A tile only ever waits for tiles with smaller ids (already running).
   const uint32_t tsum = total[0] + total[1] + total[2] + total[3];
   const uint32_t dstart0 = block_excl_scan(tsum, s_wave, nullptr);
   const uint32_t dbase0 = block_excl_scan(hcnt.x + hcnt.y + hcnt.z + hcnt.w, s_wave, nullptr);
   SORT_STAMP(2);
-  if (!closes_group) in_group_sum();                       // (their predecessors published before their own ranking: ready by now)
-  if (grp > 0u && !fail) {
-    // group words in order, nearest first, until an inclusive prefix (group 0's is one); per digit word, since the four
-    // words of a row may become visible one after the other
-    uint32_t pos[DPT] = {grp, grp, grp, grp};              // next group to consume is pos - 1; 0 = done
-    for (;;) {
-      const uint32_t top = max(max(pos[0], pos[1]), max(pos[2], pos[3]));
-      if (top == 0u) break;
-      uint4 w[LB];
-#pragma unroll
-      for (int k = 0; k < LB; ++k) if ((uint32_t)k < top) w[k] = fetch(n_tiles + top - 1u - k);
-      bool progressed = false;
-#pragma unroll
-      for (int q = 0; q < DPT; ++q) {
-        bool stop = false;
-#pragma unroll
-        for (int k = 0; k < LB; ++k) {
-          const uint32_t gidx = top - 1u - (uint32_t)k;     // the group word k holds
-          if (!stop && (uint32_t)k < top && pos[q] != 0u && gidx == pos[q] - 1u) {
-            const uint32_t x = q == 0 ? w[k].x : q == 1 ? w[k].y : q == 2 ? w[k].z : w[k].w, f = x >> 30;
-            if (f == 0u) stop = true;
-            else { excl[q] += x & ST_MASK; progressed = true; pos[q] = (f == 2u) ? 0u : pos[q] - 1u; }
-          }
-        }
-      }
-      if (!progressed) {
-        if (++spins > SPIN_LIMIT) { atomicOr(err_flag, 1u); break; }
-        __builtin_amdgcn_s_sleep(2);
-      }
-    }
-    if (closes_group) {
-      const uint32_t v[DPT] = {excl[0] + total[0], excl[1] + total[1], excl[2] + total[2], excl[3] + total[3]};
-      publish(n_tiles + grp, ST_INCL, v);
-    }
-  }
+  // LDS-staged scatter FIRST: a key's place in the tile-local sorted order needs the tile's own counts only, not the
+  // look-back - and once the keys, payloads and ranks are in LDS their ~60 registers are free for the look-back words, so
+  // the in-group words and the nearest group words travel in ONE round trip (they were two or three: the registers did not
+  // allow more; with 64 + 32 registers of look-back words beside them the kernel spilled and a pass took 34 us instead of 25).
   {
-    const uint32_t hc[DPT] = {hcnt.x, hcnt.y, hcnt.z, hcnt.w};
-    uint32_t ds = dstart0, db = dbase0;
+    uint32_t ds = dstart0;
 #pragma unroll
-    for (int q = 0; q < DPT; ++q) {
-      s_dstart[DPT * tid + q] = ds;
-      s_gbase[DPT * tid + q] = db + excl[q] - ds;
-      ds += total[q]; db += hc[q];
-    }
+    for (int q = 0; q < DPT; ++q) { s_dstart[DPT * tid + q] = ds; ds += total[q]; }
   }
   __syncthreads();
-  SORT_STAMP(3);
-
-  // LDS-staged scatter: tile-local sorted order first, then coalesced runs to HBM
 #pragma unroll
   for (int r = 0; r < SORT_KPT; ++r) {
     if ((wbase + r * 64 + lane) < n) {
@@ -412,8 +409,75 @@ void k_onesweep(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
       s_vals[pos] = val[r];
     }
   }
-  __syncthreads();
+  SORT_STAMP(3);
+  if (!closes_group) in_group_sum(true);                   // (their predecessors published before their own ranking: ready by now)
+  if (__ballot(fail) != 0ull) fail = true;                 // (the walk below runs wave-wide or not at all)
+  if (grp > 0u && !fail) {
+    // group words in order, nearest first, until an inclusive prefix (group 0's is one); per digit word, since the four
+    // words of a row may become visible one after the other
+    // (The first version of this walk predicated all 4 x 16 (digit, word) steps per lane: ~1000 VALU instructions, 4.8 us of
+    // a 25 us pass although a 256-tile pass has at most 7 group words.  Now the wave agrees on how far back anyone still has
+    // to go, rows beyond that are skipped by a scalar branch, and a step is a handful of selects.)
+    uint32_t pos[DPT] = {grp, grp, grp, grp};              // next group to consume is pos - 1; 0 = done
+    for (;;) {
+      const uint32_t top = max(max(pos[0], pos[1]), max(pos[2], pos[3]));
+      const uint32_t utop = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(top));   // farthest any lane of the wave still has to go
+      if (utop == 0u) break;
+      uint4 w[LB];
+      if (have_pre_g) {                                    // (only ever the first round: utop == grp) words 0 .. PG-1 came with the in-group words
+#pragma unroll
+        for (int k = 0; k < PG; ++k) w[k] = pre_g[k];
+#pragma unroll
+        for (int k = PG; k < LB; ++k) if ((uint32_t)k < utop) w[k] = fetch(utop - 1u - k);
+        have_pre_g = false;
+      } else {
+#pragma unroll
+        for (int k = 0; k < LB; ++k) if ((uint32_t)k < utop) w[k] = fetch(utop - 1u - k);   // word k = group utop-1-k
+      }
+      uint32_t taken[DPT] = {0u, 0u, 0u, 0u};
+      bool act[DPT], done[DPT];
+#pragma unroll
+      for (int q = 0; q < DPT; ++q) { act[q] = pos[q] != 0u; done[q] = false; }
+#pragma unroll
+      for (int k = 0; k < LB; ++k) {
+        if ((uint32_t)k < utop) {                          // scalar
+#pragma unroll
+          for (int q = 0; q < DPT; ++q) {
+            const uint32_t x = q == 0 ? w[k].x : q == 1 ? w[k].y : q == 2 ? w[k].z : w[k].w, f = x >> 30;
+            const bool on = act[q] && utop - (uint32_t)k == pos[q] - taken[q];      // word k is the next one digit q consumes
+            const bool take = on && f != 0u;
+            excl[q] += take ? (x & ST_MASK) : 0u;
+            taken[q] += take ? 1u : 0u;
+            done[q] = done[q] || (take && f == 2u);
+            act[q] = act[q] && !(on && (f == 0u || f == 2u));
+          }
+        }
+      }
+      bool progressed = false;
+#pragma unroll
+      for (int q = 0; q < DPT; ++q) { progressed = progressed || taken[q] != 0u; pos[q] = done[q] ? 0u : pos[q] - taken[q]; }
+      if (!progressed && top != 0u) {
+        if (++spins > SPIN_LIMIT) { atomicOr(err_flag, 1u); pos[0] = pos[1] = pos[2] = pos[3] = 0u; }   // (no break: the loop is wave-uniform)
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    if (closes_group) {
+      const uint32_t v[DPT] = {excl[0] + total[0], excl[1] + total[1], excl[2] + total[2], excl[3] + total[3]};
+      publish(grp, ST_INCL, v);
+    }
+  }
+  {
+    const uint32_t hc[DPT] = {hcnt.x, hcnt.y, hcnt.z, hcnt.w};
+    uint32_t ds = dstart0, db = dbase0;
+#pragma unroll
+    for (int q = 0; q < DPT; ++q) {
+      s_gbase[DPT * tid + q] = db + excl[q] - ds;
+      ds += total[q]; db += hc[q];
+    }
+  }
+  __syncthreads();                                         // the tile's sorted keys and the digits' global bases are in LDS
   SORT_STAMP(4);
+  // coalesced runs to HBM
   const uint32_t cnt = (n - base < (uint32_t)SORT_TILE) ? (n - base) : (uint32_t)SORT_TILE;
 #pragma unroll
   for (int k = 0; k < SORT_KPT; ++k) {
@@ -952,12 +1016,14 @@ static uint32_t sort_resident_tiles() {
   }
   return (uint32_t)cached;
 }
-// small sorts: all tiles run at once and latency matters (groups of 16 / 32: one or two round trips inside the group, one or
-// two over the groups); large ones: a tile's predecessors are long done, fewer words re-read
-static int sort_group_shift(uint32_t tiles) { return tiles <= 2048u ? 5 : 3; }
+// small sorts: all tiles run at once and latency matters (groups of 32: one or two round trips inside the group, one over the
+// groups); larger ones: groups of 16.  Sort time at 1.31 M / 10.5 M / 99.6 M keys with groups of 8: 90 us / 0.43 ms / 3.29 ms,
+// of 16: 79 / 0.345 / 3.14, of 32: 77 / 0.365 / -, of 64: 81 / - / -
+static int sort_group_shift(uint32_t tiles) { return tiles <= 512u ? 5 : 4; }
 static uint32_t sort_group_count(uint32_t tiles) { const int sh = sort_group_shift(tiles); return (tiles + (1u << sh) - 1u) >> sh; }
 // u32 words (used as 8-byte pairs): per pass the tiles' words, then the groups' words
-size_t rt_sort_status_words(uint32_t n) { const uint32_t t = rt_sort_tile_count(n); return (size_t)SORT_PASSES * ((size_t)t + sort_group_count(t)) * RADIX; }
+static size_t sort_pass_status_bytes(uint32_t tiles) { return (size_t)sort_group_rows_offset(tiles) + (size_t)sort_group_count(tiles) * RADIX * 4; }
+size_t rt_sort_status_words(uint32_t n) { return (size_t)SORT_PASSES * sort_pass_status_bytes(rt_sort_tile_count(n)) / 4; }
 uint32_t rt_sort_hist_words() { return (uint32_t)(SORT_PASSES * RADIX); }
 
 uint32_t rt_bounds_words() { return 6u * 2048u; }   // grid_for's block cap x 6 partials
@@ -985,9 +1051,8 @@ void rt_launch_sort(const RtBuildBuffers& b, hipStream_t s) {
   const uint32_t* ki = b.codes; const uint32_t* vi = nullptr;
   uint32_t *ko = b.keys_a, *vo = b.vals_a;
   for (int p = 0; p < SORT_PASSES; ++p) {
-    const size_t rows = (size_t)tiles + sort_group_count(tiles);
-    uint32_t* st = b.tile_status + (size_t)p * rows * RADIX;
-    const uint32_t st_bytes = (uint32_t)(rows * RADIX * sizeof(uint32_t));   // < 2^31: 65 536 tiles x 4 KB at 2^28 keys
+    const uint32_t st_bytes = (uint32_t)sort_pass_status_bytes(tiles);       // < 2^31: 52 429 tiles x 2 KB + their groups at 2^28 keys
+    uint32_t* st = b.tile_status + (size_t)p * (st_bytes / 4);
     const int gsh = sort_group_shift(tiles);
     const int ticket = tiles > sort_resident_tiles() ? 1 : 0;
     if (p == 0)

@@ -22,7 +22,7 @@ buf = np.zeros((3, 4096, 8), np.uint64)
 rc = L.rt_debug_sort_timeline(buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size))
 assert rc == 0
 print("ms_sort", st["ms_sort"], "ms_morton", st["ms_morton"])
-names = ["start->counts published", "->ranked+scans", "->look-back done", "->LDS scatter", "->stored"]
+names = ["start->counts published", "->ranked+scans", "->LDS scatter", "->look-back done", "->stored"]
 for p in range(3):
     b = buf[p].astype(np.int64)
     b = b[b[:, 5] > 0]
