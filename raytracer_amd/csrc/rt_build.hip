@@ -155,14 +155,29 @@ __global__ __launch_bounds__(BLK) void k_morton(const float* __restrict__ centro
   for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < n_status; i += (size_t)gridDim.x * BLK) tile_status[i] = 0u;
   __syncthreads();
   const V3 bmin = v3(bounds_f[0], bounds_f[1], bounds_f[2]), inv = v3(bounds_f[4], bounds_f[5], bounds_f[6]);
-  for (uint32_t t = blockIdx.x * BLK + threadIdx.x; t < n_tri; t += gridDim.x * BLK) {
-    const V3 ctr = v3(centroids[3 * (size_t)t + 0], centroids[3 * (size_t)t + 1], centroids[3 * (size_t)t + 2]);   // :52, from k_bounds
-    V3 nrm = (ctr - bmin) * inv;                                          // :55
-    uint32_t code = (expand_bits(quantize10(nrm.x)) << 2) | (expand_bits(quantize10(nrm.y)) << 1) |
-                    expand_bits(quantize10(nrm.z));                      // :58-68
-    codes[t] = code;
+  // four triangles per step, their centroids loaded before the first is used (a thread walks ~16 triangles: one at a time
+  // the loop is a chain of exposed load latencies)
+  constexpr int MU = 4;
+  const uint32_t stride = gridDim.x * BLK;
+  for (uint32_t t0 = blockIdx.x * BLK + threadIdx.x; t0 < n_tri; t0 += MU * stride) {
+    V3 ctr[MU];
 #pragma unroll
-    for (int p = 0; p < SORT_PASSES; ++p) atomicAdd(&h[p][(code >> (RADIX_BITS * p)) & (RADIX - 1)], 1u);
+    for (int u = 0; u < MU; ++u) {
+      const uint32_t t = t0 + u * stride;
+      if (t < n_tri) ctr[u] = v3(centroids[3 * (size_t)t + 0], centroids[3 * (size_t)t + 1], centroids[3 * (size_t)t + 2]);   // :52, from k_bounds
+    }
+#pragma unroll
+    for (int u = 0; u < MU; ++u) {
+      const uint32_t t = t0 + u * stride;
+      if (t < n_tri) {
+        V3 nrm = (ctr[u] - bmin) * inv;                                   // :55
+        uint32_t code = (expand_bits(quantize10(nrm.x)) << 2) | (expand_bits(quantize10(nrm.y)) << 1) |
+                        expand_bits(quantize10(nrm.z));                  // :58-68
+        codes[t] = code;
+#pragma unroll
+        for (int p = 0; p < SORT_PASSES; ++p) atomicAdd(&h[p][(code >> (RADIX_BITS * p)) & (RADIX - 1)], 1u);
+      }
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < SORT_PASSES * RADIX; i += BLK) {
