@@ -48,7 +48,8 @@ print("bench_n1:", b["value"], b["unit"], b["ms_per_step"], "ms; roofline", b["r
 # build: kernel trace + stage times, and the fabric traffic of the build kernels (same PMC passes: bench.py builds 5 times)
 for f in ("build_kernel_stats.csv", "build.txt"):
     shutil.copy(os.path.join(src, "build", f), os.path.join(dst, f))
-for f in ("build_nosurface.txt", "build_cfg5.txt", "batch_gain.txt", "batch_gain_moving.txt", "project_scaling_batch16.txt", "project_scaling_per_frame.txt"):
+for f in ("build_nosurface.txt", "build_cfg5.txt", "batch_gain.txt", "batch_gain_moving.txt", "project_scaling_batch16.txt", "project_scaling_per_frame.txt",
+          "rehearsal_n2.json", "rehearsal_n4.json"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 build_kernels = [k for k in allk if k.split("<")[0] in ("k_bounds", "k_bounds_final", "k_morton", "k_onesweep", "k_refit_local", "k_refit_mid", "k_refit_spans")]

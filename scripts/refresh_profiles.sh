@@ -26,4 +26,7 @@ echo "[9] batches, scaling projection"; timeout -k 10 300 python -u tools/batch_
 timeout -k 10 300 python -u tools/batch_gain.py --moving > "$O/batch_gain_moving.txt" 2>&1
 PROJ_BATCH=16 timeout -k 10 300 python -u tools/project_scaling.py > "$O/project_scaling_batch16.txt" 2>&1
 PROJ_BATCH=1 timeout -k 10 300 python -u tools/project_scaling.py > "$O/project_scaling_per_frame.txt" 2>&1
+echo "[10] N > 1 rehearsal on this one GPU (gloo through host memory: code path only, not a measurement)"
+scripts/rehearse_multi.sh 2 4 > "$O/rehearsal.txt" 2>&1 || true
+for n in 2 4; do [ -f "$R/gpurun_out/rehearse/bench_n$n.json" ] && tail -1 "$R/gpurun_out/rehearse/bench_n$n.json" > "$O/rehearsal_n$n.json"; done
 echo done
