@@ -106,6 +106,29 @@ def test_sortedness_and_invariants_1m(gpu_ctx):
     assert np.array_equal(nodes[~leaf][:, 4:7], np.maximum(nodes[c0][:, 4:7], nodes[c1][:, 4:7])), "box = union of children (max)"
 
 
+SORT_TILE = 5120     # keys per onesweep tile (rt_build.hip: 256 threads x RT_SORT_KPT 20)
+
+
+@pytest.mark.parametrize("n_tri,quantum", [(SORT_TILE, None), (SORT_TILE + 1, 3), (32 * SORT_TILE - 1, None), (32 * SORT_TILE, 5),
+                                           (32 * SORT_TILE + 1, None), (33 * SORT_TILE + 77, 2), (65 * SORT_TILE + 5, None),
+                                           (512 * SORT_TILE, 40), (512 * SORT_TILE + 1, None), (529 * SORT_TILE - 3, 7)])
+def test_sort_tile_and_group_boundaries(gpu_ctx, rt, n_tri, quantum):
+    """The sort's look-back has three regimes - one group (<= 32 tiles), groups of 32 (<= 512 tiles), groups of 16 (more) - and
+    its words come in two widths (u16 per tile, u32 per group): key counts right at the tile and group boundaries, with and
+    without heavy ties.  No oracle at these sizes: the order must be numpy's stable argsort of the device's own codes (which
+    the smaller cases pin to the oracle), and every node must have exactly one parent."""
+    mesh = random_soup(n_tri, 4000 + n_tri % 1009, quantum)
+    gpu_ctx.set_mesh(mesh)
+    st = gpu_ctx.build_lbvh()
+    assert st["n_tri"] == n_tri and st["refit_fallbacks"] == 0
+    codes, order = gpu_ctx.morton(), gpu_ctx.tri_order()
+    assert np.array_equal(order, np.argsort(codes, kind="stable").astype(np.uint32)), "stable sort order"
+    nodes = gpu_ctx.flatten_for_ssbo()["bvhData"]
+    leaf = nodes[:, 7] < 0
+    kids = nodes[~leaf][:, [3, 7]].astype(np.int64).reshape(-1)
+    assert leaf.sum() == n_tri and np.array_equal(np.sort(kids), np.arange(1, 2 * n_tri - 1)), "every node but the root has exactly one parent"
+
+
 def test_rebuild_is_deterministic(gpu_ctx, plane_mesh):
     gpu_ctx.set_mesh(plane_mesh)
     gpu_ctx.build_lbvh()
