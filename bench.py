@@ -354,6 +354,11 @@ def main():
         }
         if frame_check is not None:
             out["assembled_frame_vs_single_gpu_render"] = frame_check
+        if world > 1 and bframes is not None and bframes.windowed and bframes.window[0] is not None:
+            (col0, n_cols, g0, n_rows), _ = bframes.window[0]
+            out["config"]["exchange"] += (f"; only the frames' screen rectangle travels: columns {col0}..{col0 + n_cols - 1} of packed rows "
+                                          f"{g0 * rdist.STRIPE_ROWS}..{g0 * rdist.STRIPE_ROWS + n_rows - 1} of every rank = "
+                                          f"{n_rows * n_cols * 4 * world / 1e6:.1f} MB per frame instead of {frame.rpr * W * 4 * world / 1e6:.1f} MB")
         if args.rehearse_on_one_gpu and world > 1:
             out["rehearsal"] = f"{world} ranks sharing cuda:0, collectives over gloo: exercises the N > 1 code path, NOT a measurement"
         if legs:

@@ -271,6 +271,20 @@ int rt_deinterleave_device(rt_ctx* ctx, const void* d_packed, void* d_image, uin
  * de-interleave) run beside the traversal of frame i+1, which owns the context stream. */
 int rt_deinterleave_device_on(rt_ctx* ctx, void* stream, const void* d_packed, void* d_image, uint32_t width, uint32_t height,
                               uint32_t elem_bytes, int32_t stripe_rows, int32_t stripe_world, uint32_t rows_per_rank);
+/* Exchange of WINDOWS instead of whole stripe buffers (no counterpart in the reference: one GPU draws the whole canvas,
+ * web/script.js:936-945).  Most of a frame is background: pixels outside the screen rectangle of the tree's root box
+ * are misses whatever the scene holds (the cull pass of rt_render* writes them without tracing a ray).  rt_frame_rect
+ * returns that rectangle for the compute.wgsl modes ({x0, y0, x1, y1}, inclusive; x1 < x0 or y1 < y0: nothing of the tree is on screen) and the value
+ * of a missed pixel, so every rank can compute the same window from the uniforms alone and send only
+ *   columns [col0, col0 + n_cols) of its packed rows [group0 * stripe_rows, group0 * stripe_rows + n_rows)
+ * (stripe group g = the image rows [g * world * stripe_rows, (g + 1) * world * stripe_rows): one stripe of every rank).
+ * rt_assemble_device_on builds the full image from the gathered windows (rank r's window, n_rows x n_cols elements of 4
+ * bytes, at d_windows + r * rank_stride elements) and `fill` everywhere else.  cfg 3's camera: 9 MB instead of 33 MB per
+ * frame cross the links.  raytracer_amd/dist.py BatchedFrames exchanges the union window of a batch's frames. */
+int rt_frame_rect(rt_ctx* ctx, const float uniforms[44], int32_t rect[4], uint32_t* miss_rgba);
+int rt_assemble_device_on(rt_ctx* ctx, void* stream /* NULL = rt_stream() */, const void* d_windows, void* d_image, uint32_t width,
+                          uint32_t height, int32_t stripe_rows, int32_t stripe_world, uint32_t col0, uint32_t n_cols, uint32_t group0,
+                          uint32_t n_rows, uint64_t rank_stride, uint32_t fill);
 
 /* ------------------------------------------------------------------ material / texture shading (extension) */
 /* The reference shades every surface with one constant albedo (compute.wgsl:372; no WGSL reads a vt, texture or

@@ -327,6 +327,19 @@ class Context:
             self._chk(_L.rt_deinterleave_device_on(self._h, C.c_void_p(stream or None), C.c_void_p(d_packed), C.c_void_p(d_image),
                                                    width, height, elem_bytes, stripe_rows, world, rows_per_rank))
 
+    def frame_rect(self, uniforms):
+        """-> ((x0, y0, x1, y1), miss_rgba): the screen rectangle (inclusive) outside of which every pixel of the frame is a miss,
+        and the value of a missed pixel (rt_frame_rect; the compute.wgsl modes)."""
+        U = np.ascontiguousarray(uniforms, np.float32)
+        r, miss = (C.c_int32 * 4)(), C.c_uint32()
+        self._chk(_L.rt_frame_rect(self._h, _vp(U), C.byref(r), C.byref(miss)))
+        return (r[0], r[1], r[2], r[3]), miss.value
+
+    def assemble_device(self, d_windows, d_image, width, height, stripe_rows, world, col0, n_cols, group0, n_rows, rank_stride, fill, stream=None):
+        """The full image from the ranks' gathered windows (rt_assemble_device_on); stream: a hipStream_t (integer) or None."""
+        self._chk(_L.rt_assemble_device_on(self._h, C.c_void_p(stream or None), C.c_void_p(d_windows or None), C.c_void_p(d_image), width, height,
+                                           stripe_rows, world, col0, n_cols, group0, n_rows, rank_stride, fill))
+
     # ---- multi-GPU plumbing
     def bvh_view(self):
         v = _abi.BvhView()

@@ -31,7 +31,7 @@ SYMBOLS = [
     "rt_set_surface", "rt_get_tri_uv", "rt_set_tri_uv", "rt_set_materials", "rt_set_texture", "rt_tri_uv_device",
     "rt_adopt_tri_uv_device", "rt_tri_uv_export_device", "rt_set_frames_in_flight", "rt_frames_join", "rt_set_coherent_scheduling",
     "rt_render_device_noalloc",
-    "rt_render_batch_device",
+    "rt_render_batch_device", "rt_frame_rect", "rt_assemble_device_on",
 ]
 
 
@@ -149,6 +149,8 @@ def load():
         "rt_packed_rows": (u32, [u32, i32, i32, i32]),
         "rt_deinterleave_device": (C.c_int, [vp, vp, vp, u32, u32, u32, i32, i32, u32]),
         "rt_deinterleave_device_on": (C.c_int, [vp, vp, vp, vp, u32, u32, u32, i32, i32, u32]),
+        "rt_frame_rect": (C.c_int, [vp, vp, C.POINTER(C.c_int32 * 4), C.POINTER(u32)]),
+        "rt_assemble_device_on": (C.c_int, [vp, vp, vp, vp, u32, u32, i32, i32, u32, u32, u32, u32, C.c_uint64, u32]),
         "rt_bvh_view_get": (C.c_int, [vp, C.POINTER(BvhView)]),
         "rt_bvh_export_device": (C.c_int, [vp, C.POINTER(BvhView)]),
         "rt_bvh_adopt_device": (C.c_int, [vp, C.POINTER(BvhView)]),

@@ -1310,6 +1310,37 @@ extern "C" int rt_deinterleave_device_on(rt_ctx* ctx, void* stream, const void* 
   return RT_OK;
 }
 
+// Screen rectangle outside of which every pixel of the frame is a miss: what k_cull uses (rt_cull_rect), for the host.
+extern "C" int rt_frame_rect(rt_ctx* ctx, const float uniforms[44], int32_t rect[4], uint32_t* miss_rgba) {
+  NEED_BVH();
+  if (!uniforms || !rect) return ctx->fail(RT_ERR_INVALID, "rt_frame_rect: NULL argument");
+  const float fw = uniforms[36], fh = uniforms[37];
+  if (!(fw >= 1.0f) || !(fh >= 1.0f) || fw > 65536.0f || fh > 65536.0f) return ctx->fail(RT_ERR_INVALID, "resolution out of range");
+  RtRenderParams p;
+  std::memset(&p, 0, sizeof(p));
+  std::memcpy(p.U, uniforms, sizeof(float) * 44);
+  p.width = (uint32_t)fw; p.height = (uint32_t)fh;
+  rt_cull_rect(p, ctx->bvh.root_box);
+  rect[0] = p.cull_x0; rect[1] = p.cull_y0; rect[2] = p.cull_x1; rect[3] = p.cull_y1;
+  if (miss_rgba) *miss_rgba = 0xFF000000u;     // rgba8unorm of (0, 0, 0, 1), compute.wgsl:366 (the value render_frame gives k_cull)
+  return RT_OK;
+}
+
+extern "C" int rt_assemble_device_on(rt_ctx* ctx, void* stream, const void* d_windows, void* d_image, uint32_t width, uint32_t height,
+                                     int32_t stripe_rows, int32_t stripe_world, uint32_t col0, uint32_t n_cols, uint32_t group0,
+                                     uint32_t n_rows, uint64_t rank_stride, uint32_t fill) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (!d_image || width == 0 || height == 0 || stripe_rows <= 0 || stripe_world < 1) return ctx->fail(RT_ERR_INVALID, "rt_assemble_device: bad argument");
+  if ((n_cols != 0 && n_rows != 0 && !d_windows) || (uint64_t)col0 + n_cols > width ||
+      rank_stride < (uint64_t)n_rows * n_cols)
+    return ctx->fail(RT_ERR_INVALID, "rt_assemble_device: the window must lie inside the image and a rank's window must fit its stride");
+  DeviceGuard g(ctx->device);
+  rt_launch_assemble(d_windows, d_image, width, height, stripe_rows, stripe_world, col0, n_cols, group0, n_rows, (size_t)rank_stride, fill,
+                     stream ? static_cast<hipStream_t>(stream) : ctx->stream);
+  HIPCHK(hipGetLastError());
+  return RT_OK;
+}
+
 extern "C" int rt_deinterleave_device(rt_ctx* ctx, const void* d_packed, void* d_image, uint32_t width, uint32_t height,
                                       uint32_t elem_bytes, int32_t stripe_rows, int32_t stripe_world, uint32_t rows_per_rank) {
   return rt_deinterleave_device_on(ctx, nullptr, d_packed, d_image, width, height, elem_bytes, stripe_rows, stripe_world, rows_per_rank);

@@ -180,5 +180,7 @@ void rt_launch_gather_uv(const float* texcoords, const uint32_t* tex_idx, const 
                          uint32_t n_tri, float* tri_uv, hipStream_t s);
 // Conservative screen-space bound of the root box (host, double precision): fills p.cull_*.
 void rt_cull_rect(RtRenderParams& p, const float root_box[8]);
+void rt_launch_assemble(const void* windows, void* image, uint32_t width, uint32_t height, int stripe_rows, int world, uint32_t col0,
+                        uint32_t n_cols, uint32_t group0, uint32_t n_rows, size_t rank_stride, uint32_t fill, hipStream_t s);
 void rt_launch_deinterleave(const void* packed, void* image, uint32_t width, uint32_t height, uint32_t elem_bytes,
                             int stripe_rows, int world, uint32_t rows_per_rank, hipStream_t s);

@@ -1281,6 +1281,24 @@ __global__ __launch_bounds__(TBLK) void k_deinterleave(const T* __restrict__ pac
   }
 }
 
+// The same with WINDOWS instead of whole stripe buffers (rt_assemble_device_on): every rank sent only columns
+// [col0, col0 + n_cols) of its packed rows [group0 * stripe_rows, ... + n_rows) - stripe group g = image rows
+// [g * world * stripe_rows, (g + 1) * world * stripe_rows), one stripe of every rank - and everything outside is `fill`.
+__global__ __launch_bounds__(TBLK) void k_assemble(const uint32_t* __restrict__ windows, uint32_t* __restrict__ image, uint32_t width,
+                                                   uint32_t height, uint32_t stripe_rows, uint32_t world, uint32_t col0, uint32_t n_cols,
+                                                   uint32_t group0, uint32_t n_rows, size_t rank_stride, uint32_t fill) {
+  const size_t n = (size_t)width * height;
+  for (size_t i = (size_t)blockIdx.x * TBLK + threadIdx.x; i < n; i += (size_t)gridDim.x * TBLK) {
+    const uint32_t y = (uint32_t)(i / width), x = (uint32_t)(i % width);
+    const uint32_t stripe = y / stripe_rows, rin = y % stripe_rows;
+    const uint32_t rank = stripe % world, grp = stripe / world;
+    const uint32_t wr = (grp - group0) * stripe_rows + rin;              // (wraps to a huge value when grp < group0)
+    uint32_t v = fill;
+    if (grp >= group0 && wr < n_rows && x >= col0 && x - col0 < n_cols) v = windows[(size_t)rank * rank_stride + (size_t)wr * n_cols + (x - col0)];
+    image[i] = v;
+  }
+}
+
 }  // namespace
 
 // Persistent grid of phase B: what is actually resident (occupancy query), so that no block starts
@@ -1452,6 +1470,16 @@ void rt_launch_gather_uv(const float* texcoords, const uint32_t* tex_idx, const 
                          uint32_t n_tri, float* tri_uv, hipStream_t s) {
   hipLaunchKernelGGL(k_gather_uv, dim3((n_tri + TBLK - 1) / TBLK), dim3(TBLK), 0, s, texcoords, tex_idx, material_ids, order, n_tri,
                      reinterpret_cast<float4*>(tri_uv));
+}
+
+void rt_launch_assemble(const void* windows, void* image, uint32_t width, uint32_t height, int stripe_rows, int world, uint32_t col0,
+                        uint32_t n_cols, uint32_t group0, uint32_t n_rows, size_t rank_stride, uint32_t fill, hipStream_t s) {
+  const size_t n = (size_t)width * height;
+  int blocks = (int)((n + TBLK - 1) / TBLK);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_assemble, dim3(blocks), dim3(TBLK), 0, s, (const uint32_t*)windows, (uint32_t*)image, width, height,
+                     (uint32_t)stripe_rows, (uint32_t)world, col0, n_cols, group0, n_rows, rank_stride, fill);
 }
 
 void rt_launch_deinterleave(const void* packed, void* image, uint32_t width, uint32_t height, uint32_t elem_bytes,

@@ -95,6 +95,36 @@ class GpuBackend:
         if ev is not None:
             self.ext.wait_event(ev)
 
+    def frame_rect(self, U):
+        return self.ctx.frame_rect(U)
+
+    def exchange_batch_window(self, gathered, staging, packed, images, after, root_only, width, height, world, window, fill):
+        """exchange_batch with WINDOWS: only columns / rows `window` (exchange_window) of every rank's packed stripes cross the
+        links - a strided copy into `staging`, ONE collective of [B, n_rows, n_cols] per rank, and rt_assemble_device_on
+        builds each full image from the gathered windows and `fill` (the value of a missed pixel) everywhere else.
+        gathered / staging: flat buffers at least as large as the windows (gathered: world x); -> the event that ends it."""
+        col0, n_cols, group0, n_rows = window
+        n = packed.shape[0]
+        side = self.side_stream()
+        side.wait_event(after)
+        with torch.cuda.stream(side):
+            g = None
+            if n_cols > 0 and n_rows > 0:
+                per_rank = n * n_rows * n_cols
+                sub = staging.view(-1)[:per_rank].view(n, n_rows, n_cols)
+                r0 = group0 * STRIPE_ROWS
+                sub.copy_(packed[:, r0:r0 + n_rows, col0:col0 + n_cols])
+                if gathered is not None:
+                    g = gathered.view(-1)[:world * per_rank].view(world * n, n_rows, n_cols)
+                gather_stripes(g, sub, root_only)
+            if images is not None:
+                for f in range(n):    # frame f of rank r: window (r * n + f) of `g`
+                    self.ctx.assemble_device(g.data_ptr() + 4 * f * n_rows * n_cols if g is not None else 0, images[f].data_ptr(), width, height,
+                                             STRIPE_ROWS, world, col0, n_cols, group0, n_rows, n * n_rows * n_cols, fill, stream=side.cuda_stream)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return ev
+
     def exchange_batch(self, gathered, packed, images, after, root_only, width, height, world, rpr):
         """Gather of a whole batch ([B, rpr, width] per rank, ONE collective) and the de-interleave of its B frames, all on
         the side stream behind event `after`: the context stream is free to traverse the next batch meanwhile.
@@ -127,6 +157,25 @@ def all_gather_into(out, chunk):
         out.copy_(h)
     else:
         dist.all_gather_into_tensor(out, chunk)
+
+
+def exchange_window(rects, width, height, world, rpr, stripe_rows=STRIPE_ROWS):
+    """The part of every rank's packed stripes that a batch has to exchange: -> (col0, n_cols, group0, n_rows).
+    rects: the frames' (x0, y0, x1, y1) screen rectangles (inclusive) outside of which every pixel is a miss (rt_frame_rect).
+    Columns [col0, col0 + n_cols) (16-byte aligned) of the packed rows [group0 * stripe_rows, group0 * stripe_rows + n_rows)
+    hold the union of the rectangles on every rank: stripe group g is the image rows [g * world * stripe_rows, (g + 1) * world *
+    stripe_rows), one stripe of every rank, so whole groups keep the window the same on all ranks.  n_cols = 0: nothing to send."""
+    live = [r for r in rects if r[2] >= r[0] and r[3] >= r[1]]
+    if not live:
+        return 0, 0, 0, 0
+    x0, y0 = max(0, min(r[0] for r in live)), max(0, min(r[1] for r in live))
+    x1, y1 = min(width - 1, max(r[2] for r in live)), min(height - 1, max(r[3] for r in live))
+    col0 = x0 & ~3
+    n_cols = min(width - col0, (x1 + 1 - col0 + 3) & ~3)
+    rows_per_group = stripe_rows * world
+    group0, group1 = y0 // rows_per_group, y1 // rows_per_group + 1
+    n_rows = min(group1 * stripe_rows, rpr) - group0 * stripe_rows
+    return col0, n_cols, group0, n_rows
 
 
 def gather_stripes(gathered, packed, root_only):
@@ -291,7 +340,8 @@ class BatchedFrames:
     head of batch i+1 run beside the tail of batch i: 6-13 % more frames per second, tools/batch_gain.py).
     Backends without streams (the CPU oracle backend of the gloo tests) run the same steps synchronously."""
 
-    def __init__(self, backend, width, height, rank, world, batch, base_opts=None, force_collective=False, exchange="root"):
+    def __init__(self, backend, width, height, rank, world, batch, base_opts=None, force_collective=False, exchange="root",
+                 window_exchange=True):
         if exchange not in ("all", "root"):
             raise ValueError("exchange must be 'all' or 'root'")
         if not 1 <= batch <= 16:
@@ -315,6 +365,11 @@ class BatchedFrames:
         self.prev = None
         self.n_steps = 0
         self.streams = hasattr(backend, "exchange_batch")
+        # Only the union of the frames' screen rectangles is exchanged (the rest of every frame is background, known without
+        # sending it): cfg 3's camera, 9 MB instead of 33 MB per frame.  Every rank derives the same window from the uniforms.
+        self.windowed = bool(window_exchange) and self.collective and hasattr(backend, "exchange_batch_window")
+        self.staging_ring = [backend.alloc(batch * self.rpr, width) for _ in range(2)] if self.windowed else None
+        self.window = [None, None]     # per buffer set: ((col0, n_cols, group0, n_rows), fill)
 
     def step(self, Us):
         """Us: [batch, 44] uniforms.  Asynchronous; finish() before reading self.images (the frames of the LAST batch)."""
@@ -328,6 +383,9 @@ class BatchedFrames:
         packed = self.packed_ring[slot][:n]
         if self.streams:
             self.b.wait_for(self.free[slot])
+        if self.windowed:
+            rects = [self.b.frame_rect(Us[f]) for f in range(n)]
+            self.window[slot] = (exchange_window([r for r, _ in rects], self.w, self.h, self.world, self.rpr), rects[0][1])
         if hasattr(self.b, "render_packed_batch"):
             self.b.render_packed_batch(Us, self.opts, packed)
         else:
@@ -351,8 +409,13 @@ class BatchedFrames:
         if self.streams:
             after = self.rendered[slot] if self.rendered[slot] is not None else self.b.mark_batch(keep_latest)
             self.rendered[slot] = None
-            self.free[slot] = self.b.exchange_batch(gathered, packed, images, after, self.root_only,
-                                                    self.w, self.h, self.world, self.rpr)
+            if self.windowed:
+                window, fill = self.window[slot]
+                self.free[slot] = self.b.exchange_batch_window(self.gathered_ring[slot], self.staging_ring[slot], packed, images, after,
+                                                               self.root_only, self.w, self.h, self.world, window, fill)
+            else:
+                self.free[slot] = self.b.exchange_batch(gathered, packed, images, after, self.root_only,
+                                                        self.w, self.h, self.world, self.rpr)
             return
         gather_stripes(gathered.view(-1, self.w) if gathered is not None else None, packed.reshape(-1, self.w), self.root_only)
         if self.has_frame:

@@ -23,6 +23,7 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -312,8 +313,9 @@ static int run_rank(Options o, int rank, int world, Shared* sh) {
   const uint32_t rpr = world > 1 ? rt_packed_rows(H, STRIPE_ROWS, 0, world) : H;      // rank 0 always owns the most rows
   const int B = o.batch < 1 ? 1 : (o.batch > RT_MAX_BATCH ? RT_MAX_BATCH : o.batch);
   const size_t share = (size_t)rpr * W;                                               // pixels of one packed share
-  uint32_t *packed = nullptr, *gathered = nullptr, *images = nullptr;
+  uint32_t *packed = nullptr, *staging = nullptr, *gathered = nullptr, *images = nullptr;
   HIPOK(hipMalloc(reinterpret_cast<void**>(&packed), sizeof(uint32_t) * share * B));
+  HIPOK(hipMalloc(reinterpret_cast<void**>(&staging), sizeof(uint32_t) * share * B));
   HIPOK(hipMemsetAsync(packed, 0, sizeof(uint32_t) * share * B, s));
   if (rank == 0) {
     HIPOK(hipMalloc(reinterpret_cast<void**>(&gathered), sizeof(uint32_t) * share * B * world));
@@ -338,15 +340,40 @@ static int run_rank(Options o, int rank, int world, Shared* sh) {
     const int n = o.frames - f0 < B ? o.frames - f0 : B;
     for (int f = 0; f < n; ++f) outs[f] = packed + share * (size_t)f;
     RTOK(rt_render_batch_device(ctx, (uint32_t)n, Ub.data(), &ro, outs, nullptr, nullptr));
-    // gather of the batch on rank 0: rank r's n shares land at gathered[r][0 .. n)
-    NCCLOK(ncclGroupStart());
-    if (rank == 0) for (int r = 0; r < world; ++r) NCCLOK(ncclRecv(gathered + share * (size_t)n * r, share * n, ncclUint32, r, comm, s));
-    NCCLOK(ncclSend(packed, share * n, ncclUint32, 0, comm, s));
-    NCCLOK(ncclGroupEnd());
+    // Only the WINDOW of the batch crosses the links (rtcore.h, rt_frame_rect): the union of the frames' screen rectangles,
+    // widened to 16-byte columns and to whole stripe groups (one stripe of every rank) so that it is the same on all ranks.
+    int32_t x0 = (int32_t)W, y0 = (int32_t)H, x1 = -1, y1 = -1;
+    uint32_t miss = 0;
+    for (int f = 0; f < n; ++f) {
+      int32_t r[4];
+      RTOK(rt_frame_rect(ctx, Ub.data() + 44 * (size_t)f, r, &miss));
+      if (r[2] >= r[0] && r[3] >= r[1]) { x0 = std::min(x0, r[0]); y0 = std::min(y0, r[1]); x1 = std::max(x1, r[2]); y1 = std::max(y1, r[3]); }
+    }
+    uint32_t col0 = 0, n_cols = 0, group0 = 0, n_rows = 0;
+    if (x1 >= x0 && y1 >= y0) {
+      col0 = (uint32_t)std::max(x0, 0) & ~3u;
+      n_cols = std::min(W - col0, ((uint32_t)std::min<int32_t>(x1, (int32_t)W - 1) + 1u - col0 + 3u) & ~3u);
+      const uint32_t rows_per_group = (uint32_t)STRIPE_ROWS * (uint32_t)world;
+      group0 = (uint32_t)std::max(y0, 0) / rows_per_group;
+      const uint32_t group1 = (uint32_t)std::min<int32_t>(y1, (int32_t)H - 1) / rows_per_group + 1u;
+      n_rows = std::min(group1 * (uint32_t)STRIPE_ROWS, rpr) - group0 * (uint32_t)STRIPE_ROWS;
+    }
+    const size_t win = (size_t)n_rows * n_cols;                       // elements of one frame's window of one rank
+    if (win) {
+      for (int f = 0; f < n; ++f)
+        HIPOK(hipMemcpy2DAsync(staging + win * (size_t)f, sizeof(uint32_t) * n_cols,
+                               packed + share * (size_t)f + (size_t)group0 * STRIPE_ROWS * W + col0, sizeof(uint32_t) * W,
+                               sizeof(uint32_t) * n_cols, n_rows, hipMemcpyDeviceToDevice, s));
+      // gather of the batch on rank 0: rank r's n windows land at gathered[r][0 .. n)
+      NCCLOK(ncclGroupStart());
+      if (rank == 0) for (int r = 0; r < world; ++r) NCCLOK(ncclRecv(gathered + win * (size_t)n * r, win * n, ncclUint32, r, comm, s));
+      NCCLOK(ncclSend(staging, win * n, ncclUint32, 0, comm, s));
+      NCCLOK(ncclGroupEnd());
+    }
     if (rank == 0)
       for (int f = 0; f < n; ++f)
-        RTOK(rt_deinterleave_device(ctx, gathered + share * (size_t)f, images + (size_t)W * H * f, W, H, 4, world > 1 ? STRIPE_ROWS : (int32_t)H,
-                                    world, rpr * (uint32_t)n));
+        RTOK(rt_assemble_device_on(ctx, nullptr, win ? gathered + win * (size_t)f : nullptr, images + (size_t)W * H * f, W, H, STRIPE_ROWS, world,
+                                   col0, n_cols, group0, n_rows, win * (size_t)n, miss));
   }
   HIPOK(hipStreamSynchronize(s));
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (o.frames > 0 ? o.frames : 1);
@@ -364,7 +391,7 @@ static int run_rank(Options o, int rank, int world, Shared* sh) {
   }
   rt_destroy(ctx);
   NCCLOK(ncclCommDestroy(comm));
-  (void)hipFree(meta_d); (void)hipFree(blob); (void)hipFree(packed); (void)hipFree(gathered); (void)hipFree(images);
+  (void)hipFree(meta_d); (void)hipFree(blob); (void)hipFree(packed); (void)hipFree(staging); (void)hipFree(gathered); (void)hipFree(images);
   return 0;
 }
 

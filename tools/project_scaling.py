@@ -32,7 +32,8 @@ base = rt.render_opts(mode=rt.MODE_SHADOW, flags=rt.FLAG_TEXTURED)
 def run_batched(world, rank, batch, n=200):
     """The N > 1 loop of bench.py: `batch` frames per pipeline, one exchange per batch on a side stream."""
     f = rdist.BatchedFrames(rdist.GpuBackend(ctx, dev, frames_in_flight=int(os.environ.get("PROJ_BATCH_FIF", "1"))), W, H, 0, 1, batch, base,
-                            force_collective=True)       # bench.py at N > 1: one batch in flight (PROJ_BATCH_FIF=2: two)
+                            force_collective=True, window_exchange=False)   # bench.py at N > 1: one batch in flight (PROJ_BATCH_FIF=2: two);
+                                                         # whole stripes are exchanged here (the faked 1-rank image has no frame rectangle)
     rpr = rdist.rows_per_rank(H, world)
     f.rpr = rpr
     f.opts = rt.render_opts(mode=base.mode, flags=base.flags, stripe_rows=16, stripe_rank=rank, stripe_world=world)
