@@ -60,6 +60,27 @@ class GpuBackend:
     def deinterleave(self, gathered, image, width, height, world, rpr):
         self.ctx.deinterleave_device(gathered.data_ptr(), image.data_ptr(), width, height, 4, STRIPE_ROWS, world, rpr)
 
+    def gather_window(self, gathered, staging, packed, keep_latest, root_only, world, window):
+        """gather() of the frame's WINDOW only (exchange_window): a strided copy into `staging`, then the collective, on the
+        context stream behind the frame.  -> the gathered windows [world, n_rows, n_cols] (None off the root, or if empty)."""
+        col0, n_cols, group0, n_rows = window
+        self.ctx.frames_join(int(keep_latest))
+        if n_cols == 0 or n_rows == 0:
+            return None
+        with torch.cuda.stream(self.ext):
+            sub = staging.view(-1)[:n_rows * n_cols].view(n_rows, n_cols)
+            r0 = group0 * STRIPE_ROWS
+            sub.copy_(packed[r0:r0 + n_rows, col0:col0 + n_cols])
+            g = gathered.view(-1)[:world * n_rows * n_cols].view(world * n_rows, n_cols) if gathered is not None else None
+            gather_stripes(g, sub, root_only)
+        return g
+
+    def assemble(self, g, image, width, height, world, window, fill):
+        col0, n_cols, group0, n_rows = window
+        self.ctx.assemble_device(g.data_ptr() if g is not None else 0, image.data_ptr(), width, height, STRIPE_ROWS, world,
+                                 col0 if g is not None else 0, n_cols if g is not None else 0, group0, n_rows if g is not None else 0,
+                                 n_rows * n_cols, fill)
+
     def finish(self):
         self.ctx.synchronize()
         if self._side is not None:
@@ -258,7 +279,7 @@ class ShardedFrame:
 
     DEPTH = 2      # ring of packed / gathered buffers and frames kept un-gathered (more with GpuBackend(frames_in_flight > 2))
 
-    def __init__(self, backend, width, height, rank, world, base_opts=None, force_collective=False, exchange="all"):
+    def __init__(self, backend, width, height, rank, world, base_opts=None, force_collective=False, exchange="all", window_exchange=True):
         """force_collective: run the gather + de-interleave leg even at world == 1 (tests the stream plumbing on one GPU).
         exchange: "all" = every rank ends up with the frame (all_gather); "root" = only rank 0 does (self.image is None elsewhere)."""
         if exchange not in ("all", "root"):
@@ -281,9 +302,19 @@ class ShardedFrame:
         self.image = (backend.alloc(height, width) if self.has_frame else None) if self.collective else self.packed
         self.n_steps = 0
         self.pending = []              # ring slots of the frames rendered (or rendering) but not yet gathered, oldest first
+        # only the frame's screen rectangle is exchanged (see BatchedFrames); the compute.wgsl modes (rt_frame_rect)
+        self.windowed = (bool(window_exchange) and self.collective and hasattr(backend, "gather_window") and o.mode <= 2)
+        self.staging_ring = [backend.alloc(self.rpr, width) for _ in range(depth)] if self.windowed else None
+        self.window = [None] * depth
 
     def _exchange(self, slot, keep_latest):
         packed, gathered = self.packed_ring[slot], self.gathered_ring[slot]
+        if self.windowed:
+            window, fill = self.window[slot]
+            g = self.b.gather_window(gathered, self.staging_ring[slot], packed, keep_latest, self.root_only, self.world, window)
+            if self.has_frame:
+                self.b.assemble(g, self.image, self.w, self.h, self.world, window, fill)
+            return
         if hasattr(self.b, "gather"):
             self.b.gather(gathered, packed, keep_latest, self.root_only)
         else:
@@ -298,6 +329,9 @@ class ShardedFrame:
         slot = self.n_steps % len(self.packed_ring)
         self.n_steps += 1
         packed = self.packed_ring[slot]
+        if self.windowed:
+            rect, fill = self.b.frame_rect(U)
+            self.window[slot] = (exchange_window([rect], self.w, self.h, self.world, self.rpr), fill)
         st = self.b.render_packed(U, self.opts, packed, want_stats) if not want_stats else self.b.render_packed(U, self.opts, packed)
         if not self.collective:
             self.image = packed                            # world == 1: the packed rows are the frame

@@ -105,3 +105,15 @@ def test_batches_deliver_the_same_frames_with_windows_and_whole_stripes(rt, s70k
                 assert np.array_equal(got, refs[k]), (windowed, batch, f)
         if windowed:
             assert bf.window[0][0][1] < w                 # the last windows were real sub-rectangles
+        for fif in (1, 3):                                # the per-frame loop, frames in flight
+            fr = rdist.ShardedFrame(rdist.GpuBackend(s70k_ctx, dev, frames_in_flight=fif), w, h, 0, 1, opts, force_collective=True,
+                                    exchange=exchange, window_exchange=windowed)
+            assert fr.windowed == windowed
+            for k in (0, 1, 4, 3, 2, 6, 5, 4, 1):
+                fr.step(Us[k], want_stats=False)
+            fr.finish()
+            assert np.array_equal(fr.image.cpu().numpy().view(np.uint8).reshape(h, w, 4), refs[1]), (windowed, fif)
+            st = fr.step(Us[4])                           # nothing on screen, synchronous
+            fr.finish()
+            assert st["pixels"] == w * h and np.array_equal(fr.image.cpu().numpy().view(np.uint8).reshape(h, w, 4), refs[4])
+        s70k_ctx.set_frames_in_flight(1)

@@ -61,7 +61,7 @@ def run_batched(world, rank, batch, n=200):
 
 
 def run(world, rank, fif, n=200):
-    f = rdist.ShardedFrame(rdist.GpuBackend(ctx, dev, frames_in_flight=fif), W, H, 0, 1, base, force_collective=world > 1)
+    f = rdist.ShardedFrame(rdist.GpuBackend(ctx, dev, frames_in_flight=fif), W, H, 0, 1, base, force_collective=world > 1, window_exchange=False)
     if world > 1:                    # this rank's stripes, packed; the world-1 group gathers just them
         rpr = rdist.rows_per_rank(H, world)
         f.rpr = rpr
