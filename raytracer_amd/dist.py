@@ -186,11 +186,12 @@ def exchange_window(rects, width, height, world, rpr, stripe_rows=STRIPE_ROWS):
     Columns [col0, col0 + n_cols) (16-byte aligned) of the packed rows [group0 * stripe_rows, group0 * stripe_rows + n_rows)
     hold the union of the rectangles on every rank: stripe group g is the image rows [g * world * stripe_rows, (g + 1) * world *
     stripe_rows), one stripe of every rank, so whole groups keep the window the same on all ranks.  n_cols = 0: nothing to send."""
-    live = [r for r in rects if r[2] >= r[0] and r[3] >= r[1]]
+    live = [(max(r[0], 0), max(r[1], 0), min(r[2], width - 1), min(r[3], height - 1)) for r in rects]      # (clipped to the image)
+    live = [r for r in live if r[2] >= r[0] and r[3] >= r[1]]
     if not live:
         return 0, 0, 0, 0
-    x0, y0 = max(0, min(r[0] for r in live)), max(0, min(r[1] for r in live))
-    x1, y1 = min(width - 1, max(r[2] for r in live)), min(height - 1, max(r[3] for r in live))
+    x0, y0 = min(r[0] for r in live), min(r[1] for r in live)
+    x1, y1 = max(r[2] for r in live), max(r[3] for r in live)
     col0 = x0 & ~3
     n_cols = min(width - col0, (x1 + 1 - col0 + 3) & ~3)
     rows_per_group = stripe_rows * world

@@ -183,3 +183,30 @@ def test_stripe_ownership_partition():
             ys = np.concatenate([rdist.stripe_rows_of(h, r, world) for r in range(world)])
             assert np.array_equal(np.sort(ys), np.arange(h))
             assert rdist.rows_per_rank(h, world) >= max(len(rdist.stripe_rows_of(h, r, world)) for r in range(world))
+
+
+def test_exchange_window_covers_every_ranks_share_of_the_rectangles():
+    """dist.exchange_window (pure host logic): the window must hold, on EVERY rank, all packed rows / columns of the union of the
+    frames' rectangles, start on a 16-byte column, and stay inside the packed buffers."""
+    from raytracer_amd import dist as rdist
+    rng = np.random.default_rng(11)
+    for _ in range(400):
+        w, h, world = int(rng.integers(4, 400)), int(rng.integers(1, 300)), int(rng.integers(1, 9))
+        rpr = -(-(-(-h // 16)) // world) * 16          # an upper bound of rt_packed_rows(h, 16, 0, world), as the callers allocate at least
+        rects = []
+        for _f in range(int(rng.integers(1, 5))):
+            x0, y0 = int(rng.integers(-5, w + 5)), int(rng.integers(-5, h + 5))
+            rects.append((x0, y0, x0 + int(rng.integers(-3, w)), y0 + int(rng.integers(-3, h))))
+        col0, n_cols, g0, n_rows = rdist.exchange_window(rects, w, h, world, rpr)
+        live = [r for r in rects if min(r[2], w - 1) >= max(r[0], 0) and min(r[3], h - 1) >= max(r[1], 0)]      # on screen
+        if not live:
+            assert (n_cols, n_rows) == (0, 0)
+            continue
+        assert col0 % 4 == 0 and col0 + n_cols <= w and g0 * 16 + n_rows <= rpr and n_rows > 0 and n_cols > 0
+        for (x0, y0, x1, y1) in live:
+            for y in range(max(y0, 0), min(y1, h - 1) + 1):
+                stripe = y // 16
+                p = (stripe // world) * 16 + y % 16      # the packed row of image row y on its owner, rank stripe % world
+                assert g0 * 16 <= p < g0 * 16 + n_rows, (rects, w, h, world)
+            if max(x0, 0) <= min(x1, w - 1):
+                assert col0 <= max(x0, 0) and min(x1, w - 1) < col0 + n_cols
