@@ -41,6 +41,11 @@ def scene_mesh(name):
     elif name.startswith("lattice"):
         # cfg 5 of SURVEY §8d: K copies of the (normalised) cfg-3 mesh on a lattice, flattened, normalised again
         m = scenes.lattice(rt.normalize_mesh(scenes.s1m()), int(name[len("lattice"):]))
+    elif name.startswith("obj:"):
+        # a mesh file supplied out of band (bunny.obj / dragon.obj of BASELINE.md are not in the reference's tree): its MTL and
+        # the textures the MTL names are looked up beside it
+        path = name[4:]
+        m = rt.load_obj(path, os.path.dirname(os.path.abspath(path)))
     else:
         raise SystemExit(f"unknown scene {name}")
     return rt.normalize_mesh(m)          # script.js:720: every mesh is normalised into the unit cube
@@ -51,7 +56,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scene", default="s1m")
+    ap.add_argument("--scene", default="s1m", help="s1m | s70k | lattice<K> (closed-form stand-ins, SURVEY §8d) | obj:<file.obj> (a mesh supplied "
+                    "out of band; MTL and textures are looked up beside it, JPEG / PNG through PIL)")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--mode", default="shadow", choices=["primary", "shadow", "pt", "frag-web", "frag-root"],
@@ -115,7 +121,10 @@ def main():
     layout = dict(wide64=rt.LAYOUT_WIDE64, aos32=rt.LAYOUT_AOS32)[args.layout]
     W, H = args.width, args.height
     ctx = rt.Context(local)
-    textured = not args.no_texture and not frag
+    from_file = args.scene.startswith("obj:")
+    file_mesh = scene_mesh(args.scene) if from_file else None      # every rank reads the file (materials + textures are host-side data)
+    textured = not args.no_texture and not frag and (not from_file or (file_mesh.texcoords is not None and file_mesh.texcoords.size > 0
+                                                                          and file_mesh.tex_idx is not None and len(file_mesh.materials) > 0))
     tflag = rt.FLAG_TEXTURED if textured else 0
 
     # ---- hot path 1: build once on rank 0 (timed separately), replicate with RCCL
@@ -123,7 +132,7 @@ def main():
     mesh = None
     encoding = rt.NODES_V1
     if rank == 0:
-        mesh = scene_mesh(args.scene)
+        mesh = file_mesh if from_file else scene_mesh(args.scene)
         if args.encoding == "v2" or (args.encoding == "auto" and 2 * mesh.n_tri - 1 > (1 << 24)):
             encoding = rt.NODES_V2
         ctx.set_node_encoding(encoding)
@@ -149,7 +158,14 @@ def main():
         torch.cuda.synchronize()
         bcast_ms = (time.perf_counter() - t0) * 1e3
 
-    if textured:                        # materials + closed-form textures: small host-side descriptions, set on every rank
+    bound = None
+    if textured and from_file:          # the file's own materials and the images its MTL names (those that exist beside it);
+        class _SurfaceDone:             # the surface records themselves were set before the build (rank 0) / came with the BVH
+            def __init__(self, c): self.c = c
+            def set_surface(self, m): pass
+            def __getattr__(self, k): return getattr(self.c, k)
+        bound = rt.bind_obj_surface(_SurfaceDone(ctx), file_mesh, os.path.dirname(os.path.abspath(args.scene[4:])))
+    elif textured:                      # materials + closed-form textures: small host-side descriptions, set on every rank
         from raytracer_amd import scenes
         ctx.set_materials(scenes.STANDIN_MATERIALS)
         ctx.set_texture(0, scenes.procedural_texture(2048, 0))
@@ -319,7 +335,7 @@ def main():
                 "frag-root": "shader.wgsl computeLighting_optimized: 16 fixed directions x 1 bounce (roulette 0.9), 8-tap Poisson-disk light"}[args.mode]
         scene_txt = {"s1m": "cfg3: S1M closed-form icosphere stand-in for dragon.obj",
                      "s70k": "cfg1-2: S70k closed-form icosphere stand-in for bunny.obj"}.get(
-                         args.scene, f"cfg5: {args.scene[7:]} copies of S1M on a lattice, flattened")
+                         args.scene, f"mesh file {os.path.basename(args.scene[4:])}" if from_file else f"cfg5: {args.scene[7:]} copies of S1M on a lattice, flattened")
         out = {
             "metric": "Mrays/s primary+shadow, dragon.obj 4K" if (args.mode == "shadow" and args.scene == "s1m" and (W, H) == (3840, 2160))
                       else f"Mrays/s {args.mode} {args.scene} {W}x{H}",
@@ -328,7 +344,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{scene_txt} ({build['n_tri']} triangles), {W}x{H}, {what}, camera B (0,0,1.3), "
                                    f"layout {args.layout}, node records {'v2' if encoding == rt.NODES_V2 else 'v1'}, "
-                                   + ("textured shading: 3 materials, map_Kd 2048^2 + 1024^2 closed-form RGB8, nearest texel" if textured
+                                   + ((f"textured shading: the file's {len(file_mesh.materials)} materials, map_Kd images bound: {[n for n, _ in bound] or 'none found (Kd only)'}, nearest texel"
+                                       if from_file else "textured shading: 3 materials, map_Kd 2048^2 + 1024^2 closed-form RGB8, nearest texel") if textured
                                       else "constant albedo (compute.wgsl:372)"),
                        "mode": args.mode, "rays_per_frame": int(total_rays), "rays_traced_per_frame": int(total_traced), "frames_in_flight": fif, "frames_per_pipeline": batch, "stripes": "16-row round-robin" if world > 1 else "none",
                        "exchange": ("gather to rank 0" if args.exchange == "root" else "all_gather") if world > 1 else "none"},

@@ -88,6 +88,61 @@ def parse_obj(obj_text, mtl_text=None):
     return _mesh_from_handle(h)
 
 
+def load_texture(path):
+    """An image file as the RGB8 array rt_set_texture takes ([h, w, 3] uint8, row 0 = the file's first row).
+    Binary PPM (P6, maxval 255) is read here; anything else (JPEG, PNG: what the reference's MTL files name) through PIL when
+    it is installed.  The reference itself never reads a texture; this is the file side of RT_FLAG_TEXTURED."""
+    with open(path, "rb") as f:
+        head = f.read(2)
+    if head == b"P6":
+        data = open(path, "rb").read()
+        tok, pos = [], 2
+        while len(tok) < 3:                                  # width, height, maxval; '#' comments run to the end of the line
+            while data[pos:pos + 1].isspace():
+                pos += 1
+            if data[pos:pos + 1] == b"#":
+                pos = data.index(b"\n", pos) + 1
+                continue
+            end = pos
+            while not data[end:end + 1].isspace():
+                end += 1
+            tok.append(int(data[pos:end]))
+            pos = end
+        w, h, mx = tok
+        if mx != 255 or len(data) < pos + 1 + 3 * w * h:
+            raise ValueError(f"{path}: only 8-bit P6 files of the stated size are read")
+        return np.frombuffer(data, np.uint8, 3 * w * h, pos + 1).reshape(h, w, 3).copy()
+    try:
+        from PIL import Image
+    except ImportError as e:
+        raise RuntimeError(f"{path}: reading this image format needs PIL (only binary PPM is read without it)") from e
+    with Image.open(path) as im:
+        return np.ascontiguousarray(np.asarray(im.convert("RGB"), dtype=np.uint8))
+
+
+def bind_obj_surface(ctx, mesh, texture_dir, loader=load_texture):
+    """The surface of a mesh that load_obj read together with its MTL: texcoords + material ids (rt_set_surface), one material
+    record per MTL material (Kd, and a texture slot where map_Kd names a file that exists under texture_dir), the images.
+    -> the list of (map_Kd name, slot) actually bound.  Materials whose texture file is missing keep their Kd only."""
+    import os
+    ctx.set_surface(mesh)
+    slots, recs = {}, []
+    for m in mesh.materials:
+        name = m.get("map_Kd", "") if isinstance(m, dict) else ""
+        kd = m["diffuse"] if isinstance(m, dict) else m[0]
+        slot = -1
+        if name:
+            f = os.path.join(texture_dir, name.replace("\\", "/"))
+            if name in slots:
+                slot = slots[name]
+            elif os.path.isfile(f):
+                slot = slots[name] = len(slots)
+                ctx.set_texture(slot, loader(f))
+        recs.append((kd, slot))
+    ctx.set_materials(recs if recs else [((1.0, 1.0, 1.0), -1)])
+    return sorted(slots.items(), key=lambda kv: kv[1])
+
+
 def normalize_mesh(mesh):
     """normalizeMesh (script.js:207-227), in place on mesh.positions."""
     p = mesh.positions

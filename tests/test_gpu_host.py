@@ -90,3 +90,35 @@ def test_cpp_host_rccl_world1_equals_single_process(plane_obj_path, tmp_path, te
         assert info["n_gpus"] == 1 and info["frames"] == frames and info["frames_per_pipeline"] == batch
         assert info["triangles"] == single["triangles"] and info["nodes"] == single["nodes"] and info["rays"] == single["rays"]
         assert np.array_equal(_read_ppm(out), ref), f"--gpus 1 --frames {frames} --batch {batch}"
+
+
+def test_bench_runs_a_mesh_file_with_its_mtl_and_textures(tmp_path, plane_obj_path):
+    """bench.py --scene obj:<file>: a mesh supplied out of band (the reference's web/plane.obj here) with its MTL and the images the
+    MTL names beside it; the line must say which images were bound (`--no-texture`: the reference's constant albedo)."""
+    import gzip
+    import json
+    import shutil
+    import subprocess
+    import sys
+
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = tmp_path / "scene"
+    d.mkdir()
+    shutil.copy(plane_obj_path, d / "plane.obj")
+    shutil.copy(os.path.join(root, "tests", "golden", "plane_standin.mtl"), d / "plane_material.mtl")     # the name web/plane.obj's mtllib line asks for
+    rng = np.random.default_rng(5)
+    for k in (0, 1):                                     # the two images the stand-in MTL names, as binary PPM
+        img = rng.integers(0, 256, (32, 48, 3)).astype(np.uint8)
+        (d / f"standin_checker_{k}.rgb").write_bytes(b"P6\n48 32\n255\n" + img.tobytes())
+    lines = {}
+    for name, extra in (("tex", []), ("plain", ["--no-texture"])):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--scene", f"obj:{d / 'plane.obj'}", "--width", "320", "--height", "200",
+                            "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-legs", "--no-fif2"] + extra,
+                           capture_output=True, text=True, timeout=300, cwd=root)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        lines[name] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    w = lines["tex"]["config"]["workload"]
+    assert "plane.obj" in w and "standin_checker_0.rgb" in w and "standin_checker_1.rgb" in w and "6298 triangles" in w
+    assert "constant albedo" in lines["plain"]["config"]["workload"]
+    assert lines["tex"]["value"] > 0 and lines["tex"]["config"]["rays_per_frame"] == lines["plain"]["config"]["rays_per_frame"]

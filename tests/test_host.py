@@ -202,3 +202,35 @@ def test_number_parser_matches_the_reference_arithmetic(rt):
     m = rt.parse_obj("".join(f"v {t} 0 0\n" for t in toks))
     for t, got in zip(toks, m.positions[:, 0]):
         assert got == ref(t), t
+
+
+def test_load_texture_and_bind_obj_surface(rt, tmp_path):
+    """The file side of RT_FLAG_TEXTURED: binary PPM without PIL, PNG / JPEG through it; bind_obj_surface gives every MTL material
+    its Kd, a texture slot where map_Kd names a file that exists (shared between materials that name the same file), -1 else."""
+    img = np.random.default_rng(1).integers(0, 256, (5, 7, 3)).astype(np.uint8)
+    (tmp_path / "a.ppm").write_bytes(b"P6\n# a comment\n7 5\n255\n" + img.tobytes())
+    assert np.array_equal(rt.load_texture(str(tmp_path / "a.ppm")), img)
+    with pytest.raises(ValueError):
+        (tmp_path / "short.ppm").write_bytes(b"P6\n7 5\n255\n" + img.tobytes()[:50])
+        rt.load_texture(str(tmp_path / "short.ppm"))
+    try:
+        from PIL import Image
+        Image.fromarray(img).save(str(tmp_path / "b.png"))
+        assert np.array_equal(rt.load_texture(str(tmp_path / "b.png")), img)
+    except ImportError:
+        pass
+    obj = "mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nusemtl one\nf 1/1 2/2 3/3\nusemtl two\nf 2/1 4/2 3/3\nusemtl three\nf 1/1 4/2 3/3\n"
+    mtl = "newmtl one\nKd 1 0.5 0.25\nmap_Kd a.ppm\nnewmtl two\nKd 0.1 0.2 0.3\nmap_Kd missing.jpg\nnewmtl three\nKd 0.9 0.9 0.9\nmap_Kd a.ppm\n"
+    mesh = rt.parse_obj(obj, mtl)
+    assert [m["map_Kd"] for m in mesh.materials] == ["a.ppm", "missing.jpg", "a.ppm"]
+
+    class Ctx:
+        def __init__(self): self.calls = []
+        def set_surface(self, m): self.calls.append(("surface",))
+        def set_texture(self, slot, a): self.calls.append(("texture", slot, a.shape))
+        def set_materials(self, recs): self.calls.append(("materials", [(tuple(round(float(x), 3) for x in kd), s) for kd, s in recs]))
+    c = Ctx()
+    bound = rt.bind_obj_surface(c, mesh, str(tmp_path))
+    assert bound == [("a.ppm", 0)]
+    assert c.calls == [("surface",), ("texture", 0, (5, 7, 3)),
+                       ("materials", [((1.0, 0.5, 0.25), 0), ((0.1, 0.2, 0.3), -1), ((0.9, 0.9, 0.9), 0)])]
