@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 3   /* 2: rt_render_stats.pixels_traced, rt_render_device_noalloc, cache-file trailer; 3: rt_render_batch_device (up to 16 frames) */
+#define RT_ABI_VERSION 4   /* 2: rt_render_stats.pixels_traced, rt_render_device_noalloc, cache-file trailer; 3: rt_render_batch_device (up to 16 frames); 4: rt_frame_rect, rt_assemble_device_on */
 
 enum {
   RT_OK = 0,
