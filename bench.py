@@ -71,9 +71,9 @@ def main():
                     help="asynchronous frames in flight per GPU (rtcore.h rt_set_frames_in_flight). auto = 1 on one GPU, so that every "
                          "k_render launch runs alone and its duration is the kernel's own (roofline), 3 with N > 1, where a rank's "
                          "share of the frame is small and mostly tail (3 frame streams + the context stream = the 4 hardware queues)")
-    ap.add_argument("--batch", default="auto", choices=["auto"] + [str(k) for k in range(1, 17)],
-                    help="frames per pipeline (rtcore.h rt_render_batch_device). auto = 16 (RT_MAX_BATCH): the K steps run as ceil(K / 16) "
-                         "pipelines of equal size (K = 20: 10 + 10), each ONE k_render launch over the pixel lists of its frames (a frame, and even more a rank's "
+    ap.add_argument("--batch", default="auto", choices=["auto"] + [str(k) for k in range(1, 33)],
+                    help="frames per pipeline (rtcore.h rt_render_batch_device). auto = 32 (RT_MAX_BATCH) on one GPU, 16 with N > 1: the K steps run as "
+                         "ceil(K / batch) pipelines of equal size (K = 20: one pipeline of 20; N > 1: 10 + 10), each ONE k_render launch over the pixel lists of its frames (a frame, and even more a rank's "
                          "stripe share of one, is mostly launch overhead + idle tail on its own: tools/batch_gain.py); with N > 1 one "
                          "exchange per batch on a side stream.  1 = one frame per pipeline (the `per_frame` leg at N = 1)")
     ap.add_argument("--exchange", default="root", choices=["root", "all"],
@@ -178,7 +178,9 @@ def main():
         shade.gi_samples = args.spp
     shade = dict(gi_samples=shade.gi_samples, gi_bounces=shade.gi_bounces, soft_samples=shade.soft_samples, max_stack=shade.max_stack)
     base = rt.render_opts(mode=mode, layout=layout, flags=tflag, **shade)
-    batch = (1 if frag else 16) if args.batch == "auto" else int(args.batch)     # the older fragment shaders run one frame per pipeline
+    # auto: 32 (RT_MAX_BATCH) on one GPU - K = 20 steps are ONE pipeline; 16 with N > 1, where two pipelines (10 + 10) let the
+    # exchange of the first overlap the traversal of the second; the older fragment shaders run one frame per pipeline
+    batch = (1 if frag else (32 if world == 1 else 16)) if args.batch == "auto" else int(args.batch)
     if frag and batch > 1:
         raise SystemExit("--batch > 1 renders through rt_render_batch_device: --mode primary|shadow|pt only")
     # pipelines (frames, or batches of frames) in flight: 1 at N = 1, so that every k_render launch runs alone and its duration is
@@ -256,7 +258,7 @@ def main():
     # the same K frames again with two frames in flight (only where the main loop ran with one): whole-job throughput when
     # the tail of one frame may overlap the head of the next; reported beside `value`, never as `value` at N = 1
     fif2 = None
-    if fif == 1 and world == 1 and not args.no_fif2:
+    if fif == 1 and world == 1 and not args.no_fif2 and (batch == 1 or len(rdist.batch_sizes(args.steps, batch)) > 1):   # (one pipeline: nothing to overlap)
         b2 = rdist.GpuBackend(ctx, device, frames_in_flight=2)
         if batch > 1:                   # two BATCHES in flight: cull / compaction and the head of batch i+1 beside the tail of batch i
             frame2 = rdist.BatchedFrames(b2, W, H, rank, world, batch, base)

@@ -260,7 +260,7 @@ int rt_render_device_noalloc(rt_ctx* ctx, const float uniforms[44], const rt_ren
  * asynchronous on rt_stream() - or, with rt_set_frames_in_flight(n >= 2), on the frame streams under the ordering rules
  * given there (a batch counts as one frame: the tail of batch i overlaps the head of batch i+1); the scheduling hints
  * left behind are those of the last frame, and a batch whose views differ is not ordered by hints at all. */
-#define RT_MAX_BATCH 16
+#define RT_MAX_BATCH 32
 int rt_render_batch_device(rt_ctx* ctx, uint32_t n_frames, const float* uniforms /* [n_frames][44] */, const rt_render_opts* opts,
                            void* const* d_rgba8, void* const* d_hit_tri, void* const* d_hit_t);
 /* De-interleave `world` packed stripe buffers (concatenated rank-major, each

@@ -124,6 +124,7 @@ struct rt_ctx {
   // render scratch, one set per frame slot (slot 0 = the context stream; slots 0/1 alternate with two frames in flight)
   static constexpr int MAX_FIF = 4;            // frame slots (rt_set_frames_in_flight)
   DevBuf<uint32_t> r_tile_counter[MAX_FIF], r_list[MAX_FIF];
+  DevBuf<RtFrameRec> r_frames[MAX_FIF];        // a batch's per-frame records (rt_internal.h)
   DevBuf<float4> pt_recs[MAX_FIF];             // PT split records (rt_trace.hip), per frame slot
   DevBuf<float> pt_terms[MAX_FIF];
   DevBuf<unsigned long long> r_stats[MAX_FIF];
@@ -277,7 +278,7 @@ extern "C" void rt_destroy(rt_ctx* ctx) {
   for (auto& t : ctx->texels) t.release();
   ctx->tex_table.release();
   for (int k = 0; k < rt_ctx::MAX_FIF; ++k) {
-    ctx->r_tile_counter[k].release(); ctx->r_list[k].release(); ctx->r_stats[k].release(); ctx->pt_recs[k].release(); ctx->pt_terms[k].release();
+    ctx->r_tile_counter[k].release(); ctx->r_list[k].release(); ctx->r_frames[k].release(); ctx->r_stats[k].release(); ctx->pt_recs[k].release(); ctx->pt_terms[k].release();
     if (ctx->fstream[k]) { (void)hipStreamSynchronize(ctx->fstream[k]); (void)hipStreamDestroy(ctx->fstream[k]); }
     if (ctx->f_done[k]) (void)hipEventDestroy(ctx->f_done[k]);
   }
@@ -1073,21 +1074,23 @@ int render_batch(rt_ctx* ctx, uint32_t n_frames, const float* uniforms, const rt
   RtBatch bt;
   std::memset(&bt, 0, sizeof(bt));
   bt.n = n_frames;
+  RtFrameRec recs[RT_MAX_BATCH];
+  std::memset(recs, 0, sizeof(RtFrameRec) * n_frames);
   for (uint32_t f = 0; f < n_frames; ++f) {
     const float* U = uniforms + 44 * (size_t)f;
     if (U[36] != fw || U[37] != fh) return ctx->fail(RT_ERR_INVALID, "rt_render_batch_device: every frame of a batch has the same resolution (frame " + std::to_string(f) + " differs)");
     void* o[3] = {d_rgba8 ? d_rgba8[f] : nullptr, d_hit_tri ? d_hit_tri[f] : nullptr, d_hit_t ? d_hit_t[f] : nullptr};
     if (((reinterpret_cast<uintptr_t>(o[0]) | reinterpret_cast<uintptr_t>(o[1]) | reinterpret_cast<uintptr_t>(o[2])) & 3u) != 0u)
       return ctx->fail(RT_ERR_INVALID, "output pointers must be 4-byte aligned");
-    std::memcpy(bt.U[f], U, sizeof(float) * RT_U_FLOATS);
-    bt.rgba8[f] = static_cast<uint8_t*>(o[0]); bt.hit_tri[f] = static_cast<uint32_t*>(o[1]); bt.hit_t[f] = static_cast<float*>(o[2]);
+    std::memcpy(recs[f].U, U, sizeof(float) * RT_U_FLOATS);
+    recs[f].rgba8 = static_cast<uint8_t*>(o[0]); recs[f].hit_tri = static_cast<uint32_t*>(o[1]); recs[f].hit_t = static_cast<float*>(o[2]);
   }
   DeviceGuard g(ctx->device);
   RtRenderParams p;
   std::memset(&p, 0, sizeof(p));
   rc = fill_scene_params(ctx, opts, p, /*alloc_tables=*/true);
   if (rc != RT_OK) return rc;
-  std::memcpy(p.U, uniforms, sizeof(float) * 44);               // (the kernels of a batch read bt.U[f])
+  std::memcpy(p.U, uniforms, sizeof(float) * 44);               // (the kernels of a batch read bt.frames[f].U)
   p.mode = opts->mode; p.gi_samples = opts->gi_samples; p.gi_bounces = opts->gi_bounces; p.soft_samples = opts->soft_samples;
   p.max_stack = opts->max_stack;
   p.miss_rgba = 0xFF000000u;
@@ -1156,8 +1159,11 @@ int render_batch(rt_ctx* ctx, uint32_t n_frames, const float* uniforms, const rt
     RtRenderParams pf = p;
     std::memcpy(pf.U, uniforms + 44 * (size_t)f, sizeof(float) * 44);
     rt_cull_rect(pf, ctx->bvh.root_box);
-    bt.cull[f][0] = pf.cull_x0; bt.cull[f][1] = pf.cull_x1; bt.cull[f][2] = pf.cull_y0; bt.cull[f][3] = pf.cull_y1;
+    recs[f].cull[0] = pf.cull_x0; recs[f].cull[1] = pf.cull_x1; recs[f].cull[2] = pf.cull_y0; recs[f].cull[3] = pf.cull_y1;
   }
+  HIPCHK(ctx->r_frames[slot].ensure(RT_MAX_BATCH));
+  rt_launch_put_frames(recs, n_frames, ctx->r_frames[slot].p, s);     // (the slot's previous batch ran on this same stream: in order)
+  bt.frames = ctx->r_frames[slot].p;
   hipEvent_t* E = nullptr;   // {batch begin, k_render begin, k_render end, batch end}: rt_profile_end reports per batch
   if (ctx->prof_on) { E = &ctx->prof_ev[4 * (size_t)(ctx->prof_n % rt_ctx::PROF_RING)]; ctx->prof_n += 1; }
   if (E) HIPCHK(hipEventRecord(E[0], s));

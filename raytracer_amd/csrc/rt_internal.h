@@ -96,19 +96,26 @@ struct RtRenderParams {
 
 // Several frames of one shape in one frame pipeline (rt_render_batch_device): k_cull / k_compact run with the frame as
 // grid.y over per-frame scratch regions, ONE persistent k_render walks all the frames' pixel lists, hottest class of every
-// frame first.  Passed by value next to RtRenderParams (whose U / outputs / cull rectangle are then unused).
+// frame first.  RtBatch is passed by value next to RtRenderParams (whose U / outputs / cull rectangle are then unused); what
+// differs between the frames lives in DEVICE memory, one 200-byte record per frame (a launch carries at most 4 KB of
+// arguments: 16 records; rt_render_batch_device writes them with k_put_frames, 16 per launch, ahead of the pipeline).
 constexpr int RT_U_FLOATS = 40;
+struct RtFrameRec {
+  float     U[RT_U_FLOATS];  // the uniform floats the kernels read: 0 .. 38 (compute.wgsl:4-13), padded to 40
+  uint8_t*  rgba8;
+  uint32_t* hit_tri;
+  float*    hit_t;
+  int       cull[4];         // x0, x1, y0, y1
+};
+constexpr int RT_FRAMES_PER_PUT = 16;
+struct RtFrameChunk { RtFrameRec r[RT_FRAMES_PER_PUT]; };
 struct RtBatch {
   uint32_t n;
   uint32_t mask_stride;      // u64 words between the frames' tile-mask arrays
   uint32_t bt_stride;        // u32 words between the frames' block totals
   uint32_t list_stride;      // u32 words between the frames' pixel lists
   uint32_t lc_stride;        // u32 words between the frames' list_count blocks
-  float     U[RT_MAX_BATCH][RT_U_FLOATS];   // the uniform floats the kernels read: 0 .. 38 (compute.wgsl:4-13), padded to 40
-  uint8_t*  rgba8[RT_MAX_BATCH];
-  uint32_t* hit_tri[RT_MAX_BATCH];
-  float*    hit_t[RT_MAX_BATCH];
-  int       cull[RT_MAX_BATCH][4];   // x0, x1, y0, y1 per frame
+  const RtFrameRec* frames;  // [n], device memory
 };
 struct RtNoBatch {};
 constexpr uint32_t RT_LC_WORDS = 32;   // list_count block of a frame: [0] entries, [1] hottest-class entries, [2..7] class thresholds,
@@ -175,6 +182,7 @@ void rt_launch_render(const RtRenderParams& p, int layout, bool count_work, bool
 // the same pipeline over bt.n frames (no stats, no PT split, compute.wgsl modes only)
 void rt_launch_render_batch(const RtRenderParams& p, const RtBatch& bt, int layout, int n_cu, hipStream_t s,
                             hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+void rt_launch_put_frames(const RtFrameRec* host_recs, uint32_t n, RtFrameRec* d_frames, hipStream_t s);
 // BVH-order surface records: record i <- input triangle order[i]
 void rt_launch_gather_uv(const float* texcoords, const uint32_t* tex_idx, const int32_t* material_ids, const uint32_t* order,
                          uint32_t n_tri, float* tri_uv, hipStream_t s);

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 
 #include "rt_device.h"
@@ -729,8 +730,9 @@ template <bool BATCH, typename B>
 RT_DEV FrameView frame_view(const RtRenderParams& p, const B& bt, uint32_t f) {
   FrameView v;
   if constexpr (BATCH) {
-    v.U = bt.U[f]; v.rgba8 = bt.rgba8[f]; v.hit_tri = bt.hit_tri[f]; v.hit_t = bt.hit_t[f];
-    v.cull_x0 = bt.cull[f][0]; v.cull_x1 = bt.cull[f][1]; v.cull_y0 = bt.cull[f][2]; v.cull_y1 = bt.cull[f][3];
+    const RtFrameRec& r = bt.frames[f];                    // f is wave-uniform: scalar loads
+    v.U = r.U; v.rgba8 = r.rgba8; v.hit_tri = r.hit_tri; v.hit_t = r.hit_t;
+    v.cull_x0 = r.cull[0]; v.cull_x1 = r.cull[1]; v.cull_y0 = r.cull[2]; v.cull_y1 = r.cull[3];
     v.masks = p.masks + (size_t)f * bt.mask_stride; v.block_total = p.block_total + (size_t)f * bt.bt_stride;
     v.list = p.list + (size_t)f * bt.list_stride; v.list_count = p.list_count + (size_t)f * bt.lc_stride;
   } else {
@@ -1024,7 +1026,7 @@ template <int LAYOUT, bool COUNT, bool TEX, int KIND, bool BATCH = false, typena
 __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p, const B bt) {
   constexpr bool PTSPLIT = KIND == KIND_PTSPLIT;
   static_assert(!BATCH || KIND == KIND_PIXEL, "a batch runs the compute.wgsl pixel kind only");
-  static_assert(RT_MAX_BATCH * N_CLASS <= 64, "a batch's run table (frames x cost classes) is one wavefront wide");
+  constexpr int RPL = (RT_MAX_BATCH * N_CLASS + 63) / 64;   // runs (frame x cost class) of a batch's run table per lane
   extern __shared__ __align__(16) unsigned char smem[];
 #ifdef RT_TIMELINE
   const unsigned long long tl_start = wall_clock64();
@@ -1058,25 +1060,31 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p, const B
   // frames' lists, hottest class of EVERY frame first (class-major, frame-minor), each run cut into its own chunks; lane o
   // holds run o's first chunk, and a chunk id finds its run with one ballot.
   uint32_t n_list = 0, n_chunks = 0;
-  uint32_t seg_first = 0xFFFFFFFFu, seg_start = 0, seg_count = 0, seg_frame = 0;   // BATCH: my run (lane = class rank * n + frame)
+  uint32_t seg_first[RPL], seg_start[RPL], seg_count[RPL], seg_frame[RPL];   // BATCH: my runs (run r * 64 + lane = class rank * n + frame)
+#pragma unroll
+  for (int r = 0; r < RPL; ++r) { seg_first[r] = 0xFFFFFFFFu; seg_start[r] = seg_count[r] = seg_frame[r] = 0u; }
   if constexpr (!BATCH) {
     n_list = *p.list_count;                              // written by k_compact (previous launch on this stream)
     n_chunks = (n_list + 63u) / 64u;
   } else {
     const uint32_t n_seg = bt.n * (uint32_t)N_CLASS;
-    uint32_t my_chunks = 0;
-    if ((uint32_t)lane < n_seg) {
-      seg_frame = (uint32_t)lane % bt.n;
-      const uint32_t c = (uint32_t)(N_CLASS - 1) - (uint32_t)lane / bt.n;              // hottest class first, cheap / unknown (0) last
-      const uint32_t* lc = p.list_count + (size_t)seg_frame * bt.lc_stride;
-      seg_start = lc[8 + c]; seg_count = lc[16 + c];
-      my_chunks = (seg_count + 63u) / 64u;
-    }
-    uint32_t inc = my_chunks;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, o); if (lane >= o) inc += t; }
-    n_chunks = (uint32_t)__shfl((int)inc, 63);
-    seg_first = ((uint32_t)lane < n_seg && my_chunks > 0u) ? inc - my_chunks : 0xFFFFFFFFu;   // empty runs never match
+    for (int r = 0; r < RPL; ++r) {
+      const uint32_t run = (uint32_t)r * 64u + (uint32_t)lane;
+      uint32_t my_chunks = 0;
+      if (run < n_seg) {
+        seg_frame[r] = run % bt.n;
+        const uint32_t c = (uint32_t)(N_CLASS - 1) - run / bt.n;                        // hottest class first, cheap / unknown (0) last
+        const uint32_t* lc = p.list_count + (size_t)seg_frame[r] * bt.lc_stride;
+        seg_start[r] = lc[8 + c]; seg_count[r] = lc[16 + c];
+        my_chunks = (seg_count[r] + 63u) / 64u;
+      }
+      uint32_t inc = my_chunks;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, o); if (lane >= o) inc += t; }
+      seg_first[r] = (run < n_seg && my_chunks > 0u) ? n_chunks + inc - my_chunks : 0xFFFFFFFFu;   // empty runs never match
+      n_chunks += (uint32_t)__shfl((int)inc, 63);
+    }
   }
   const uint32_t per_xcd = (gridDim.x + 7u) / 8u;
   int shard = (int)((blockIdx.x & 7u) * (N_SHARD / 8) + ((blockIdx.x >> 3) * (N_SHARD / 8)) / per_xcd) & (N_SHARD - 1);
@@ -1102,9 +1110,16 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p, const B
       bool last_frame = true;
       if constexpr (!BATCH) { li = chunk * 64u + (uint32_t)lane; li_end = n_list; }
       else {
-        const int o = 63 - __clzll((long long)__ballot(seg_first <= chunk));          // the last run that starts at or before this chunk (empty runs never match)
-        const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)seg_frame, o));
-        const uint32_t first = (uint32_t)__shfl((int)seg_first, o), start = (uint32_t)__shfl((int)seg_start, o), cnt = (uint32_t)__shfl((int)seg_count, o);
+        // the last run that starts at or before this chunk (empty runs never match); chunk is wave-uniform, so are the branches
+        uint32_t my_frame = seg_frame[0], my_first = seg_first[0], my_start = seg_start[0], my_count = seg_count[0];
+        int o = 63 - __clzll((long long)__ballot(seg_first[0] <= chunk));
+#pragma unroll
+        for (int r = 1; r < RPL; ++r) {
+          const unsigned long long m = __ballot(seg_first[r] <= chunk);
+          if (m) { o = 63 - __clzll((long long)m); my_frame = seg_frame[r]; my_first = seg_first[r]; my_start = seg_start[r]; my_count = seg_count[r]; }
+        }
+        const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)my_frame, o));
+        const uint32_t first = (uint32_t)__shfl((int)my_first, o), start = (uint32_t)__shfl((int)my_start, o), cnt = (uint32_t)__shfl((int)my_count, o);
         fv = frame_view<true>(p, bt, f);
         li = start + (chunk - first) * 64u + (uint32_t)lane; li_end = start + cnt;
         time_h = (float)hash_u32(sat_u32(fv.U[38]));
@@ -1279,6 +1294,15 @@ __global__ __launch_bounds__(TBLK) void k_deinterleave(const T* __restrict__ pac
     const size_t src = ((size_t)rank * rows_per_rank + (size_t)sl * stripe_rows + rin) * width + x;
     image[i] = packed[src];
   }
+}
+
+// The frame records of a batch, 16 per launch as kernel arguments, into the batch's device array.
+__global__ __launch_bounds__(64) void k_put_frames(const RtFrameChunk c, RtFrameRec* __restrict__ dst, uint32_t n) {
+  constexpr uint32_t WORDS = sizeof(RtFrameRec) / 4u;
+  static_assert(sizeof(RtFrameRec) % 8 == 0 && sizeof(RtFrameChunk) <= 3584, "frame records travel as kernel arguments");
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(&c);
+  uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+  for (uint32_t i = threadIdx.x; i < n * WORDS; i += 64u) d[i] = src[i];
 }
 
 // The same with WINDOWS instead of whole stripe buffers (rt_assemble_device_on): every rank sent only columns
@@ -1470,6 +1494,16 @@ void rt_launch_gather_uv(const float* texcoords, const uint32_t* tex_idx, const 
                          uint32_t n_tri, float* tri_uv, hipStream_t s) {
   hipLaunchKernelGGL(k_gather_uv, dim3((n_tri + TBLK - 1) / TBLK), dim3(TBLK), 0, s, texcoords, tex_idx, material_ids, order, n_tri,
                      reinterpret_cast<float4*>(tri_uv));
+}
+
+void rt_launch_put_frames(const RtFrameRec* host_recs, uint32_t n, RtFrameRec* d_frames, hipStream_t s) {
+  for (uint32_t f0 = 0; f0 < n; f0 += RT_FRAMES_PER_PUT) {
+    RtFrameChunk c;
+    const uint32_t k = std::min<uint32_t>(RT_FRAMES_PER_PUT, n - f0);
+    std::memset(&c, 0, sizeof(c));
+    std::memcpy(c.r, host_recs + f0, sizeof(RtFrameRec) * k);
+    hipLaunchKernelGGL(k_put_frames, dim3(1), dim3(64), 0, s, c, d_frames + f0, k);
+  }
 }
 
 void rt_launch_assemble(const void* windows, void* image, uint32_t width, uint32_t height, int stripe_rows, int world, uint32_t col0,

@@ -379,8 +379,8 @@ class BatchedFrames:
                  window_exchange=True):
         if exchange not in ("all", "root"):
             raise ValueError("exchange must be 'all' or 'root'")
-        if not 1 <= batch <= 16:
-            raise ValueError("batch must be in [1, 16] (RT_MAX_BATCH)")
+        if not 1 <= batch <= 32:
+            raise ValueError("batch must be in [1, 32] (RT_MAX_BATCH)")
         self.b, self.w, self.h, self.rank, self.world, self.batch = backend, width, height, rank, world, batch
         self.root_only = exchange == "root"
         self.has_frame = rank == 0 or not self.root_only

@@ -27,13 +27,13 @@ main = [k for k in allk if k.startswith("k_render<0, false, true, 0, true")]    
 assert len(main) == 1, list(allk)
 ks_bench = json.loads(open(os.path.join(src, "ks", "bench.json")).read().strip().splitlines()[-1])
 # launches of the batch kernel in one pass of `--steps 20 --warmup 5`: set-up batch (16 frames), warm-up (5), timed (10 + 10)
-FRAMES_PER_LAUNCH = (16 + 5 + 10 + 10) / 4.0
+FRAMES_PER_LAUNCH = (32 + 5 + 20) / 3.0        # the batch kernel's launches in `bench.py --steps 20 --warmup 5`: set-up 32, warm-up 5, timed 20
 t = {"workload": {"scene": "s1m", "width": 3840, "height": 2160, "mode": "shadow", "layout": "wide64", "spp": 32, "textured": True,
-                  "frames_per_pipeline": 16},
+                  "frames_per_pipeline": 32},
      "frames_per_launch": FRAMES_PER_LAUNCH,
      "source": f"profiles/{RND}/pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE and lane passes of `python3 bench.py --no-cpu-baseline "
                "--no-fif2 --no-legs --steps 20 --warmup 5`, scripts/pmc_passes.sh; per LAUNCH of the batch kernel, a launch holding "
-               f"{FRAMES_PER_LAUNCH} frames on average: set-up 16, warm-up 5, timed 10 + 10)",
+               f"{FRAMES_PER_LAUNCH} frames on average: set-up 32, warm-up 5, timed 20)",
      "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md, HBM/rocprofv3: gfx950 FETCH_SIZE reports half of the "
                    "bytes read; Infinity-Cache hits are counted, so this is fabric-side traffic, an upper bound on HBM bytes)",
      "k_render_fetch_size_kb_raw": allk[main[0]]["fetch_size_kb_raw"], "k_render_write_size_kb_raw": allk[main[0]]["write_size_kb_raw"],

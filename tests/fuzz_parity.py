@@ -72,7 +72,7 @@ def run(n_cases, seed0, log=print):
     gi, nb, soft = int(rng.integers(1, 5)), int(rng.integers(0, 4)), int(rng.integers(1, 6))
     if frag:
         w, h, gi, nb = min(w, 48), min(h, 40), int(rng.integers(1, 4)), min(nb, 2)      # the fragment shaders' GI loops are long
-    n_frames = int(rng.integers(1, 17))
+    n_frames = int(rng.integers(1, 33)) if case % 4 == 0 else int(rng.integers(1, 17))
     world = int(rng.choice([1, 1, 2, 3]))
     rank = int(rng.integers(0, world))
     params = dict(case=case, seed=seed0 + case, kind=kind, T=T, enc=enc, mode=mode, layout=layout, stack=stack, w=w, h=h, gi=gi, nb=nb,

@@ -73,7 +73,7 @@ def test_batch_equals_per_frame_rendering(rt, oracle):
         _same(_batch(ctx, torch, Us, shadow), ref, "shadow, hints off")
         ctx.set_coherent_scheduling(True)
         # every batch size, the same view 8 times, and a batch after single frames of another shape
-        for n in (1, 2, 8, 11, 16):
+        for n in (1, 2, 8, 11, 16, 17, 20, 32):     # 17+: the frame records no longer fit one launch's arguments, the run table one wavefront
             Un = _views(rt, 483, 271, n)
             _same(_batch(ctx, torch, Un, shadow), _single(ctx, torch, Un, shadow), f"shadow, {n} frames")
         same8 = [Us[1]] * 8
@@ -154,7 +154,7 @@ def test_batch_rejects_what_it_does_not_define(rt, plane_mesh):
                                 None, None, None)
         ctx.synchronize()
         with pytest.raises(rt.RtError) as e:
-            ctx.render_batch_device(np.stack([U] * 17), o, None, None, None)
+            ctx.render_batch_device(np.stack([U] * 33), o, None, None, None)
         assert e.value.code == -1 and "n_frames" in str(e.value)
         with pytest.raises(rt.RtError) as e:
             ctx.render_batch_device(np.stack([U, rt.make_uniforms(64, 72, **PLANE_VIEW)]), o, None, None, None)

@@ -29,15 +29,15 @@ def case(name, mesh, W, H, stripe=None, stripe_rows=16):
     oc = rt.render_opts(mode=rt.MODE_SHADOW, flags=rt.FLAG_TEXTURED | rt.FLAG_COUNT_WORK, **so)
     rows = rt.packed_rows(H, stripe_rows, *stripe) if stripe else H
     views = [rt.make_uniforms(W, H, cam_pos=(0.0, 0.0, 1.3), rot_deg=(0.0, (1.0 * k if moving else 0.0), 0.0)) for k in range(8)]
-    bufs = torch.empty((16, rows, W), dtype=torch.int32, device=dev)
+    bufs = torch.empty((32, rows, W), dtype=torch.int32, device=dev)
     c = ctx.render_device(views[0], oc, d_rgba8=bufs[0].data_ptr())
     byts = 32 * c["box_tests"] + 48 * c["tri_tests"] + 48 * c["hit_updates"] + 4 * c["pixels"] - 36 * (c["pixels"] - c["pixels_traced"])
     n = 240
     print(f"{name:28s} traced pixels {c['pixels_traced']}, rays {c['rays_primary'] + c['rays_shadow']}, algorithmic bytes {byts / 1e6:.1f} MB", flush=True)
 
-    def report(tag, e, tr_ms, launches):
-        per_frame = tr_ms * launches / n
-        print(f"{name:28s} {tag:22s} {e / n * 1e3:8.4f} ms/frame  k_render {per_frame:7.4f} ms/frame  frac {byts / (per_frame * 1e-3) / 1e9 / 8000:6.3f}", flush=True)
+    def report(tag, e, tr_ms, launches, frames=n):
+        per_frame = tr_ms * launches / frames
+        print(f"{name:28s} {tag:22s} {e / frames * 1e3:8.4f} ms/frame  k_render {per_frame:7.4f} ms/frame  frac {byts / (per_frame * 1e-3) / 1e9 / 8000:6.3f}", flush=True)
 
     for fif in (1, 3):
         ctx.set_frames_in_flight(fif)
@@ -52,7 +52,7 @@ def case(name, mesh, W, H, stripe=None, stripe_rows=16):
         e = time.perf_counter() - t0
         _, tr, k = ctx.profile_end()
         report(f"per frame, {fif} in flight", e, tr, k)
-    for fif, sizes in ((1, (2, 4, 8, 16)), (2, (8, 16))):
+    for fif, sizes in ((1, (2, 4, 8, 16, 20, 32)), (2, (8, 16))):
       ctx.set_frames_in_flight(fif)
       for B in sizes:
           ptrs = [bufs[f].data_ptr() for f in range(B)]
@@ -67,7 +67,7 @@ def case(name, mesh, W, H, stripe=None, stripe_rows=16):
           (ctx.frames_join(0), ctx.synchronize())
           e = time.perf_counter() - t0
           _, tr, k = ctx.profile_end()
-          report(f"batch of {B}" + (f", {fif} in flight" if fif > 1 else ""), e, tr, k)
+          report(f"batch of {B}" + (f", {fif} in flight" if fif > 1 else ""), e, tr, k, (n // B) * B)
 
     ctx.set_frames_in_flight(1)
     ctx.close()
