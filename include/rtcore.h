@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 4   /* 2: rt_render_stats.pixels_traced, rt_render_device_noalloc, cache-file trailer; 3: rt_render_batch_device (up to 16 frames); 4: rt_frame_rect, rt_assemble_device_on */
+#define RT_ABI_VERSION 4   /* 2: rt_render_stats.pixels_traced, rt_render_device_noalloc, cache-file trailer; 3: rt_render_batch_device; 4: rt_frame_rect, rt_assemble_device_on, RT_MAX_BATCH 32 */
 
 enum {
   RT_OK = 0,
@@ -255,7 +255,9 @@ int rt_render_device_noalloc(rt_ctx* ctx, const float uniforms[44], const rt_ren
  * cull and compaction passes run as one launch each and ONE persistent traversal launch drains all the frames' pixel
  * lists (the hottest pixels of every frame first), so the launch overheads and the idle tail of a frame are paid once
  * per batch: this is the entry point for small frames / stripe shares (a 1/8 share of a 4K frame is ~0.1 ms of work).
- * Per frame of a 16-frame batch against per-frame launches (one MI355X): 4K 0.43 -> 0.26 ms, 1080p 0.25 -> 0.072 ms.
+ * Per frame of a 32-frame batch against per-frame launches (one MI355X): 4K 0.44 -> 0.26 ms, 1080p 0.26 -> 0.064 ms.
+ * (What differs between the frames - uniforms, output pointers - is copied into device memory ahead of the pipeline: the
+ * uniforms and pointer arrays are free again when the call returns.)
  * RT_MODE_PRIMARY / SHADOW / PT only (PT runs one lane per pixel); no statistics (RT_FLAG_COUNT_WORK is refused);
  * asynchronous on rt_stream() - or, with rt_set_frames_in_flight(n >= 2), on the frame streams under the ordering rules
  * given there (a batch counts as one frame: the tail of batch i overlaps the head of batch i+1); the scheduling hints
