@@ -990,6 +990,11 @@ __global__ __launch_bounds__(TBLK) void k_compact(const RtRenderParams p, const 
     }
   }
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  // most blocks of a frame lie outside the root box's screen rectangle and have nothing to list (cfg 3: 4 of 5)
+  unsigned long long mine_any = 0ull;
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) mine_any |= my_mask[i];
+  if (!__syncthreads_or(mine_any != 0ull)) return;
 #pragma unroll 1
   for (int r = 0; r < CULL_TPB / (TBLK / 64); ++r) {
     const int k = r * (TBLK / 64) + w;
