@@ -372,7 +372,10 @@ def main():
                          # small share of the HBM roof, and the VALU lanes are half idle behind divergent 64-byte gathers
                          "fabric_frac": (round(pmc["k_render_hbm_bytes_per_launch"] / (trav_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
                                          if pmc.get("k_render_hbm_bytes_per_launch") and trav_ms > 0 else None),
-                         "valu_lane_util": pmc.get("k_render_valu_lane_util")},
+                         "valu_lane_util": pmc.get("k_render_valu_lane_util"),
+                         "note": "achieved = SURVEY 8d's algorithmic bytes (32 B per box test, 48 per triangle test, 48 per hit update, 4 per pixel) / "
+                                 "kernel time; the records come out of L2 / Infinity Cache (fabric traffic = `traffic`, ~17x less), so frac can "
+                                 "pass 1: the kernel is bound by dependent 64-byte gathers, not by HBM"},
         }
         if frame_check is not None:
             out["assembled_frame_vs_single_gpu_render"] = frame_check
