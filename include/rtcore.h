@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 4   /* 2: rt_render_stats.pixels_traced, rt_render_device_noalloc, cache-file trailer; 3: rt_render_batch_device; 4: rt_frame_rect, rt_assemble_device_on, RT_MAX_BATCH 32 */
+#define RT_ABI_VERSION 5   /* 5: rt_material carries all of material_t + texture options;
+                              2: rt_render_stats.pixels_traced, rt_render_device_noalloc, cache-file trailer; 3: rt_render_batch_device; 4: rt_frame_rect, rt_assemble_device_on, RT_MAX_BATCH 32 */
 
 enum {
   RT_OK = 0,
@@ -68,14 +69,41 @@ typedef struct rt_mesh_view {
   uint32_t        n_tri;
   uint32_t        n_materials;
 } rt_mesh_view;
-typedef struct rt_material {                     /* subset of tinyobj::material_t (tiny_obj_loader.h:188-247) */
-  char  name[128];
-  float diffuse[3];                              /* Kd */
+/* tinyobj::texture_option_t (tiny_obj_loader.h:166-186), filled by ParseTextureNameAndOption (:1411-1528): the options of a
+ * map_* / bump / disp / refl / norm line that stand IN FRONT of the file name (what follows the name belongs to the name). */
+typedef struct rt_texopt {
+  int32_t type;               /* -type: 0 none, 1 sphere, 2 cube_top, 3 cube_bottom, 4 cube_front, 5 cube_back, 6 cube_left, 7 cube_right */
+  float   sharpness;          /* -boost (1) */
+  float   brightness;         /* -mm base (0) */
+  float   contrast;           /* -mm gain (1) */
+  float   origin_offset[3];   /* -o u v w (0 0 0) */
+  float   scale[3];           /* -s u v w (1 1 1) */
+  float   turbulence[3];      /* -t u v w (0 0 0) */
+  int32_t texture_resolution; /* -texres (-1) */
+  int32_t clamp;              /* -clamp on|off (0) */
+  int32_t blendu, blendv;     /* -blendu / -blendv on|off (1) */
+  float   bump_multiplier;    /* -bm (1) */
+  char    imfchan;            /* -imfchan: 'l' for the bump map, 'm' otherwise */
+  char    colorspace[31];     /* -colorspace (empty) */
+} rt_texopt;
+/* the thirteen texture names of material_t, in the order LoadMtl tests their keys (:2600-2747) */
+enum { RT_MAP_KA = 0 /* map_Ka */, RT_MAP_KD /* map_Kd */, RT_MAP_KS /* map_Ks */, RT_MAP_NS /* map_Ns */,
+       RT_MAP_BUMP /* map_bump, map_Bump, bump */, RT_MAP_DISP /* map_disp, map_Disp, disp */, RT_MAP_D /* map_d */, RT_MAP_REFL /* refl */,
+       RT_MAP_PR /* map_Pr */, RT_MAP_PM /* map_Pm */, RT_MAP_PS /* map_Ps */, RT_MAP_KE /* map_Ke */, RT_MAP_NORM /* norm */, RT_N_MAPS };
+typedef struct rt_material {                     /* tinyobj::material_t (tiny_obj_loader.h:188-247), as LoadMtl (:2322-2773) fills it */
+  char  name[128];                               /* newmtl: ONE word (parseString) */
+  float diffuse[3];                              /* Kd; (0,0,0) without a Kd line, (0.6,0.6,0.6) when a map_Kd line comes before any Kd (:2617) */
   float emission[3];                             /* Ke */
-  float dissolve;                                /* d / 1-Tr */
+  float dissolve;                                /* d, or 1 - Tr when no d came before it (`d` wins, :2524) */
   int   illum;
-  char  diffuse_texname[256];                    /* map_Kd */
-  char  bump_texname[256];                       /* map_Bump / bump */
+  char  diffuse_texname[256];                    /* = texname[RT_MAP_KD] */
+  char  bump_texname[256];                       /* = texname[RT_MAP_BUMP] */
+  /* ABI 5: the rest of material_t.  Names longer than 255 bytes are cut (unbounded strings there). */
+  float ambient[3], specular[3], transmittance[3];   /* Ka, Ks, Kt / Tf */
+  float shininess, ior;                          /* Ns (1), Ni (1) */
+  float roughness, metallic, sheen, clearcoat_thickness, clearcoat_roughness, anisotropy, anisotropy_rotation;   /* Pr Pm Ps Pc Pcr aniso anisor */
+  char  texname[RT_N_MAPS][256];
+  rt_texopt texopt[RT_N_MAPS];
 } rt_material;
 
 int  rt_mesh_load_obj(const char* obj_path, const char* mtl_search_dir /* NULL = dir of obj */,

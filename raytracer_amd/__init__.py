@@ -56,9 +56,15 @@ def _mesh_from_handle(h):
                 key, val = C.c_char_p(), C.c_char_p()
                 _L.rt_mesh_material_unknown(h, i, k, C.byref(key), C.byref(val))
                 unknown[key.value.decode()] = val.value.decode()
-            mats.append(dict(name=m.name.decode(), diffuse=tuple(m.diffuse), emission=tuple(m.emission), dissolve=m.dissolve,
-                             illum=m.illum, map_Kd=m.diffuse_texname.decode(), map_Bump=m.bump_texname.decode(),
-                             unknown_parameter=unknown))
+            d = dict(name=m.name.decode(), diffuse=tuple(m.diffuse), emission=tuple(m.emission), dissolve=m.dissolve,
+                     illum=m.illum, ambient=tuple(m.ambient), specular=tuple(m.specular), transmittance=tuple(m.transmittance),
+                     shininess=m.shininess, ior=m.ior, roughness=m.roughness, metallic=m.metallic, sheen=m.sheen,
+                     clearcoat_thickness=m.clearcoat_thickness, clearcoat_roughness=m.clearcoat_roughness,
+                     anisotropy=m.anisotropy, anisotropy_rotation=m.anisotropy_rotation, unknown_parameter=unknown)
+            for k, key in enumerate(_abi.MAP_KEYS):            # the thirteen texture names + options of material_t
+                d[key] = m.texname[k].value.decode()
+                d[key + "_opt"] = m.texopt[k].as_dict()
+            mats.append(d)
         return Mesh(arr(v.positions, 3 * v.n_vert, np.float32), arr(v.normals, 3 * v.n_nor, np.float32),
                     arr(v.vert_idx, 3 * v.n_tri, np.uint32), arr(v.nor_idx, 3 * v.n_tri, np.uint32),
                     arr(v.texcoords, 2 * v.n_tex, np.float32), arr(v.tex_idx, 3 * v.n_tri, np.uint32),

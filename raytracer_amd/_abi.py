@@ -43,10 +43,34 @@ class MeshView(C.Structure):
                 ("material_ids", C.POINTER(C.c_int32)), ("n_tri", C.c_uint32), ("n_materials", C.c_uint32)]
 
 
+N_MAPS = 13
+MAP_KEYS = ("map_Ka", "map_Kd", "map_Ks", "map_Ns", "map_Bump", "disp", "map_d", "refl", "map_Pr", "map_Pm", "map_Ps", "map_Ke", "norm")   # RT_MAP_* order
+
+
+class TexOpt(C.Structure):
+    _fields_ = [("type", C.c_int32), ("sharpness", C.c_float), ("brightness", C.c_float), ("contrast", C.c_float),
+                ("origin_offset", C.c_float * 3), ("scale", C.c_float * 3), ("turbulence", C.c_float * 3),
+                ("texture_resolution", C.c_int32), ("clamp", C.c_int32), ("blendu", C.c_int32), ("blendv", C.c_int32),
+                ("bump_multiplier", C.c_float), ("imfchan", C.c_char), ("colorspace", C.c_char * 31)]
+
+    def as_dict(self):
+        d = {n: getattr(self, n) for n, _ in self._fields_}
+        for k in ("origin_offset", "scale", "turbulence"):
+            d[k] = tuple(d[k])
+        d["imfchan"] = d["imfchan"].decode()
+        d["colorspace"] = d["colorspace"].decode()
+        return d
+
+
 class Material(C.Structure):
     _fields_ = [("name", C.c_char * 128), ("diffuse", C.c_float * 3), ("emission", C.c_float * 3),
                 ("dissolve", C.c_float), ("illum", C.c_int), ("diffuse_texname", C.c_char * 256),
-                ("bump_texname", C.c_char * 256)]
+                ("bump_texname", C.c_char * 256),
+                ("ambient", C.c_float * 3), ("specular", C.c_float * 3), ("transmittance", C.c_float * 3),
+                ("shininess", C.c_float), ("ior", C.c_float)] + \
+               [(n, C.c_float) for n in ("roughness", "metallic", "sheen", "clearcoat_thickness", "clearcoat_roughness",
+                                         "anisotropy", "anisotropy_rotation")] + \
+               [("texname", (C.c_char * 256) * N_MAPS), ("texopt", TexOpt * N_MAPS)]
 
 
 class Camera(C.Structure):

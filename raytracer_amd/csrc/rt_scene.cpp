@@ -16,6 +16,7 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <set>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -145,60 +146,180 @@ bool parse_corner(const char*& p, int nv, int nvn, int nvt, Corner* c) {
   return true;
 }
 
-// keys LoadMtl consumes itself (tiny_obj_loader.h:2385-2747); any other `key<blank>value` line lands in unknown_parameter
-bool mtl_key_known(const std::string& k) {
-  static const char* known[] = {"newmtl", "Ka", "Kd", "Ks", "Kt", "Tf", "Ni", "Ke", "Ns", "illum", "d", "Tr", "Pr", "Pm", "Ps", "Pc", "Pcr",
-                                "aniso", "anisor", "map_Ka", "map_Kd", "map_Ks", "map_Ns", "map_bump", "map_Bump", "bump", "map_d",
-                                "map_disp", "map_Disp", "disp", "refl", "map_Pr", "map_Pm", "map_Ps", "map_Ke", "norm"};
-  for (const char* x : known) if (k == x) return true;
-  return false;
+// ---- LoadMtl, tiny_obj_loader.h:2322-2773, restated branch by branch (same order of the key tests, same IS_SPACE guards) ----
+inline bool is_eol(char c) { return c == '\r' || c == '\n' || c == 0; }                 // IS_NEW_LINE :850
+inline bool key_is(const char* t, const char* key) {                                   // strncmp(token, key, n) == 0 && IS_SPACE(token[n])
+  const size_t n = std::strlen(key);
+  return std::strncmp(t, key, n) == 0 && is_blank(t[n]);
+}
+float mtl_real(const char*& t, double dflt = 0.0) {                                    // parseReal :1124-1133
+  Cursor c{t};
+  const float v = c.real(dflt);
+  t = c.p;
+  return v;
+}
+std::string mtl_word(const char*& t) {                                                 // parseString :909-917
+  Cursor c{t};
+  std::string s = c.word();
+  t = c.p;
+  return s;
+}
+int mtl_int(const char*& t) {                                                          // parseInt :919-925
+  while (is_blank(*t)) ++t;
+  const int i = atoi(t);
+  while (*t && *t != ' ' && *t != '\t' && *t != '\r') ++t;
+  return i;
+}
+bool mtl_on_off(const char*& t) {                                                      // parseOnOff :1224-1241, called with default_value = true
+  while (is_blank(*t)) ++t;
+  bool ret = true;
+  if (std::strncmp(t, "on", 2) == 0) ret = true;
+  else if (std::strncmp(t, "off", 3) == 0) ret = false;
+  while (*t && *t != ' ' && *t != '\t' && *t != '\r') ++t;
+  return ret;
+}
+int mtl_texture_type(const char*& t) {                                                 // parseTextureType :1243-1281 (prefix matches, in its order)
+  while (is_blank(*t)) ++t;
+  static const struct { const char* name; int ty; } types[] = {{"cube_top", 2}, {"cube_bottom", 3}, {"cube_left", 6}, {"cube_right", 7},
+                                                               {"cube_front", 4}, {"cube_back", 5}, {"sphere", 1}};
+  int ty = 0;
+  for (const auto& k : types) if (std::strncmp(t, k.name, std::strlen(k.name)) == 0) { ty = k.ty; break; }
+  while (*t && *t != ' ' && *t != '\t' && *t != '\r') ++t;
+  return ty;
+}
+void init_texopt(rt_texopt* o, bool is_bump) {                                         // InitTexOpt :1530-1558
+  std::memset(o, 0, sizeof(*o));
+  o->imfchan = is_bump ? 'l' : 'm';
+  o->bump_multiplier = 1.0f; o->clamp = 0; o->blendu = 1; o->blendv = 1; o->sharpness = 1.0f; o->brightness = 0.0f; o->contrast = 1.0f;
+  for (int i = 0; i < 3; ++i) { o->origin_offset[i] = 0.0f; o->scale[i] = 1.0f; o->turbulence[i] = 0.0f; }
+  o->texture_resolution = -1; o->type = 0;
+}
+// ParseTextureNameAndOption :1411-1528.  Options are recognised only IN FRONT of the file name; the name is everything from the
+// first token that is no option to the end of the line (blanks and later "-options" included).  -> false: no name on the line
+// (*texname is then left as it was).
+bool parse_texture_name_and_option(std::string* texname, rt_texopt* o, const char* linebuf) {
+  bool found = false;
+  std::string name;
+  const char* t = linebuf;
+  while (!is_eol(*t)) {
+    while (is_blank(*t)) ++t;
+    if (key_is(t, "-blendu")) { t += 8; o->blendu = mtl_on_off(t) ? 1 : 0; }
+    else if (key_is(t, "-blendv")) { t += 8; o->blendv = mtl_on_off(t) ? 1 : 0; }
+    else if (key_is(t, "-clamp")) { t += 7; o->clamp = mtl_on_off(t) ? 1 : 0; }
+    else if (key_is(t, "-boost")) { t += 7; o->sharpness = mtl_real(t, 1.0); }
+    else if (key_is(t, "-bm")) { t += 4; o->bump_multiplier = mtl_real(t, 1.0); }
+    else if (key_is(t, "-o")) { t += 3; for (int i = 0; i < 3; ++i) o->origin_offset[i] = mtl_real(t, 0.0); }
+    else if (key_is(t, "-s")) { t += 3; for (int i = 0; i < 3; ++i) o->scale[i] = mtl_real(t, 1.0); }
+    else if (key_is(t, "-t")) { t += 3; for (int i = 0; i < 3; ++i) o->turbulence[i] = mtl_real(t, 0.0); }
+    else if (key_is(t, "-type")) { t += 5; o->type = mtl_texture_type(t); }
+    else if (key_is(t, "-texres")) { t += 7; o->texture_resolution = mtl_int(t); }
+    else if (key_is(t, "-imfchan")) {
+      t += 9;
+      while (is_blank(*t)) ++t;
+      const char* e = t;
+      while (*e && *e != ' ' && *e != '\t' && *e != '\r') ++e;
+      if (e - t == 1) o->imfchan = *t;
+      t = e;
+    }
+    else if (key_is(t, "-mm")) { t += 4; o->brightness = mtl_real(t, 0.0); o->contrast = mtl_real(t, 1.0); }
+    else if (key_is(t, "-colorspace")) { t += 12; std::snprintf(o->colorspace, sizeof(o->colorspace), "%s", mtl_word(t).c_str()); }
+    else { name = std::string(t); t += name.size(); found = true; }
+  }
+  if (found) *texname = name;
+  return found;
 }
 
+void init_material(rt_material* m) {                                                   // InitMaterial :1560-1612
+  std::memset(m, 0, sizeof(*m));
+  for (int k = 0; k < RT_N_MAPS; ++k) init_texopt(&m->texopt[k], k == RT_MAP_BUMP);
+  m->illum = 0; m->dissolve = 1.0f; m->shininess = 1.0f; m->ior = 1.0f;              // every colour, Kd included, starts at 0 (:1585-1592)
+}
+
+// materials / unknown: appended to; by_name: material_map (std::map::insert keeps the FIRST material of a name, :2390, :2765)
 void parse_mtl(const std::string& text, std::vector<rt_material>& mats, std::vector<std::map<std::string, std::string>>& unknown,
                std::map<std::string, int>& by_name) {
   std::istringstream in(text);
   std::string line;
-  rt_material cur;
+  rt_material cur;                       // "Create a default material anyway" (:2328): lines in front of the first newmtl land in it
+  std::string cur_name, texname[RT_N_MAPS];
   std::map<std::string, std::string> cur_unknown;
-  bool have = false;
-  auto reset = [&](const std::string& name) {
-    std::memset(&cur, 0, sizeof(cur));
-    std::snprintf(cur.name, sizeof(cur.name), "%s", name.c_str());
-    cur.diffuse[0] = cur.diffuse[1] = cur.diffuse[2] = 0.6f;   // tinyobj InitMaterial leaves 0; Kd is normally present
-    cur.dissolve = 1.0f;
-    cur.illum = 0;
-    cur_unknown.clear();
+  bool has_d = false, has_tr = false, has_kd = false;
+  init_material(&cur);
+  auto flush = [&]() {
+    std::snprintf(cur.name, sizeof(cur.name), "%s", cur_name.c_str());
+    for (int k = 0; k < RT_N_MAPS; ++k) std::snprintf(cur.texname[k], sizeof(cur.texname[k]), "%s", texname[k].c_str());
+    std::snprintf(cur.diffuse_texname, sizeof(cur.diffuse_texname), "%s", texname[RT_MAP_KD].c_str());
+    std::snprintf(cur.bump_texname, sizeof(cur.bump_texname), "%s", texname[RT_MAP_BUMP].c_str());
+    by_name.insert(std::make_pair(cur_name, (int)mats.size()));
+    mats.push_back(cur); unknown.push_back(cur_unknown);
   };
-  auto flush = [&]() { if (have) { by_name[cur.name] = (int)mats.size(); mats.push_back(cur); unknown.push_back(cur_unknown); } };
+  auto real3 = [&](const char*& t, float* v) { for (int i = 0; i < 3; ++i) v[i] = mtl_real(t, 0.0); };
+  auto tex = [&](int k, const char* t) { parse_texture_name_and_option(&texname[k], &cur.texopt[k], t); };
   while (std::getline(in, line)) {
-    // trailing blanks, then one '\r', go first (tiny_obj_loader.h:2349-2365)
+    // trailing blanks, then one '\r', go first (:2349-2365)
     line.erase(line.find_last_not_of(" \t") + 1);
     if (!line.empty() && line.back() == '\r') line.pop_back();
-    Cursor c{line.c_str()};
-    c.skip_blank();
-    if (*c.p == 0 || *c.p == '#') continue;
-    const char* token = c.p;
-    std::string key = c.word();
-    if (key == "newmtl") { flush(); reset(c.rest()); have = true; }
-    else if (!have) continue;
-    else if (key == "Kd") { for (int i = 0; i < 3; ++i) cur.diffuse[i] = c.real(); }
-    else if (key == "Ke") { for (int i = 0; i < 3; ++i) cur.emission[i] = c.real(); }
-    else if (key == "d") { cur.dissolve = c.real(1.0); }
-    else if (key == "Tr") { cur.dissolve = 1.0f - c.real(0.0); }
-    else if (key == "illum") { cur.illum = atoi(c.word().c_str()); }
-    else if (key == "map_Kd") { std::snprintf(cur.diffuse_texname, sizeof(cur.diffuse_texname), "%s", c.rest().c_str()); }
-    else if (key == "map_Bump" || key == "map_bump" || key == "bump") {
-      std::snprintf(cur.bump_texname, sizeof(cur.bump_texname), "%s", c.rest().c_str());
+    const char* t = line.c_str();
+    while (is_blank(*t)) ++t;
+    if (*t == 0 || *t == '#') continue;
+    if (key_is(t, "newmtl")) {                                    // :2385-2417: the previous material is kept only if it has a name
+      if (!cur_name.empty()) flush();
+      init_material(&cur); cur_unknown.clear();
+      for (auto& n : texname) n.clear();
+      has_d = has_tr = has_kd = false;
+      t += 7;
+      cur_name = mtl_word(t);                                     // ONE word (parseString), not the rest of the line
+      continue;
     }
-    else if (!mtl_key_known(key)) {
-      // tiny_obj_loader.h:2749-2762: the key ends at the first ' ' of the line (at the first '\t' only when the line has
-      // no ' ' at all), the value is everything behind that one character; map::insert keeps the first value of a key
-      const char* sep = std::strchr(token, ' ');
-      if (!sep) sep = std::strchr(token, '\t');
-      if (sep) cur_unknown.insert(std::make_pair(std::string(token, (size_t)(sep - token)), std::string(sep + 1)));
+    if (t[0] == 'K' && t[1] == 'a' && is_blank(t[2])) { t += 2; real3(t, cur.ambient); continue; }
+    if (t[0] == 'K' && t[1] == 'd' && is_blank(t[2])) { t += 2; real3(t, cur.diffuse); has_kd = true; continue; }
+    if (t[0] == 'K' && t[1] == 's' && is_blank(t[2])) { t += 2; real3(t, cur.specular); continue; }
+    if ((t[0] == 'K' && t[1] == 't' && is_blank(t[2])) || (t[0] == 'T' && t[1] == 'f' && is_blank(t[2]))) { t += 2; real3(t, cur.transmittance); continue; }
+    if (t[0] == 'N' && t[1] == 'i' && is_blank(t[2])) { t += 2; cur.ior = mtl_real(t); continue; }
+    if (t[0] == 'K' && t[1] == 'e' && is_blank(t[2])) { t += 2; real3(t, cur.emission); continue; }
+    if (t[0] == 'N' && t[1] == 's' && is_blank(t[2])) { t += 2; cur.shininess = mtl_real(t); continue; }
+    if (key_is(t, "illum")) { t += 6; cur.illum = mtl_int(t); continue; }
+    if (t[0] == 'd' && is_blank(t[1])) { t += 1; cur.dissolve = mtl_real(t); has_d = true; continue; }           // :2506-2520
+    if (t[0] == 'T' && t[1] == 'r' && is_blank(t[2])) {                                                          // :2521-2541: `d` wins
+      t += 2;
+      if (!has_d) cur.dissolve = 1.0f - mtl_real(t);
+      has_tr = true;
+      continue;
     }
+    if (t[0] == 'P' && t[1] == 'r' && is_blank(t[2])) { t += 2; cur.roughness = mtl_real(t); continue; }
+    if (t[0] == 'P' && t[1] == 'm' && is_blank(t[2])) { t += 2; cur.metallic = mtl_real(t); continue; }
+    if (t[0] == 'P' && t[1] == 's' && is_blank(t[2])) { t += 2; cur.sheen = mtl_real(t); continue; }
+    if (t[0] == 'P' && t[1] == 'c' && is_blank(t[2])) { t += 2; cur.clearcoat_thickness = mtl_real(t); continue; }
+    if (key_is(t, "Pcr")) { t += 4; cur.clearcoat_roughness = mtl_real(t); continue; }
+    if (key_is(t, "aniso")) { t += 6; cur.anisotropy = mtl_real(t); continue; }
+    if (key_is(t, "anisor")) { t += 7; cur.anisotropy_rotation = mtl_real(t); continue; }
+    if (key_is(t, "map_Ka")) { tex(RT_MAP_KA, t + 7); continue; }
+    if (key_is(t, "map_Kd")) {                                    // :2609-2625: 0.6 only when no Kd line came BEFORE this one
+      tex(RT_MAP_KD, t + 7);
+      if (!has_kd) cur.diffuse[0] = cur.diffuse[1] = cur.diffuse[2] = 0.6f;
+      continue;
+    }
+    if (key_is(t, "map_Ks")) { tex(RT_MAP_KS, t + 7); continue; }
+    if (key_is(t, "map_Ns")) { tex(RT_MAP_NS, t + 7); continue; }
+    if (key_is(t, "map_bump") || key_is(t, "map_Bump")) { tex(RT_MAP_BUMP, t + 9); continue; }
+    if (key_is(t, "bump")) { tex(RT_MAP_BUMP, t + 5); continue; }
+    if (key_is(t, "map_d")) { t += 6; texname[RT_MAP_D] = t; tex(RT_MAP_D, t); continue; }   // :2666-2673: the raw rest first
+    if (key_is(t, "map_disp") || key_is(t, "map_Disp")) { tex(RT_MAP_DISP, t + 9); continue; }
+    if (key_is(t, "disp")) { tex(RT_MAP_DISP, t + 5); continue; }
+    if (key_is(t, "refl")) { tex(RT_MAP_REFL, t + 5); continue; }
+    if (key_is(t, "map_Pr")) { tex(RT_MAP_PR, t + 7); continue; }
+    if (key_is(t, "map_Pm")) { tex(RT_MAP_PM, t + 7); continue; }
+    if (key_is(t, "map_Ps")) { tex(RT_MAP_PS, t + 7); continue; }
+    if (key_is(t, "map_Ke")) { tex(RT_MAP_KE, t + 7); continue; }
+    if (key_is(t, "norm")) { tex(RT_MAP_NORM, t + 5); continue; }
+    // :2749-2762: the key ends at the first ' ' of the line (at the first '\t' only when the line has no ' ' at all), the
+    // value is everything behind that one character; map::insert keeps the first value of a key
+    const char* sep = std::strchr(t, ' ');
+    if (!sep) sep = std::strchr(t, '\t');
+    if (sep) cur_unknown.insert(std::make_pair(std::string(t, (size_t)(sep - t)), std::string(sep + 1)));
   }
-  flush();
+  (void)has_tr;
+  flush();                                                        // :2764-2767: the last material always, named or not
 }
 
 // Point-in-polygon test of tiny_obj_loader.h:1616-1628 (W. R. Franklin's pnpoly) on a triangle, f32 as there.
@@ -274,6 +395,7 @@ int parse_obj(const std::string& text, const std::string* mtl_text, const std::s
               rt_mesh** out, char* err, size_t err_len) {
   auto* m = new rt_mesh();
   std::map<std::string, int> mat_by_name;
+  std::set<std::string> mtl_loaded;
   if (mtl_text) parse_mtl(*mtl_text, m->materials, m->unknown, mat_by_name);
   std::vector<Corner> face;
   int cur_mat = -1;
@@ -346,20 +468,36 @@ int parse_obj(const std::string& text, const std::string* mtl_text, const std::s
         ear_clip(m->pos.data(), vi, tris);
         for (size_t i = 0; i + 2 < tris.size(); i += 3) emit(tris[i], tris[i + 1], tris[i + 2]);
       }
-    } else if (!strncmp(t, "usemtl", 6) && is_blank(t[6])) {
-      c.p = t + 7;
-      std::string name = c.rest();
+    } else if (!strncmp(t, "usemtl", 6)) {              // tiny_obj_loader.h:3200-3233: no blank needed behind the key; ONE word
+      const char* q = t + 6;
+      const std::string name = mtl_word(q);
       auto it = mat_by_name.find(name);
-      cur_mat = (it == mat_by_name.end()) ? -1 : it->second;
+      cur_mat = (it == mat_by_name.end()) ? -1 : it->second;   // unknown name: a warning there, material id -1
     } else if (!strncmp(t, "mtllib", 6) && is_blank(t[6])) {
+      // :3236-3303: the rest of the line split at ' ' ('\' escapes a character; tabs do not split); the files are tried in
+      // order, the first one that opens is loaded and ends the search; a file loaded before is not loaded again
       if (!mtl_text && !mtl_dir.empty()) {
-        c.p = t + 7;
-        std::string fn = c.rest();
-        std::ifstream f(mtl_dir + "/" + fn, std::ios::binary);
-        if (f) {
+        std::string rest(t + 7);
+        while (!rest.empty() && (rest.back() == '\r' || rest.back() == '\n')) rest.pop_back();
+        std::vector<std::string> names;
+        std::string tok;
+        bool esc = false;
+        for (char ch : rest) {
+          if (esc) esc = false;
+          else if (ch == '\\') { esc = true; continue; }
+          else if (ch == ' ') { if (!tok.empty()) names.push_back(tok); tok.clear(); continue; }
+          tok += ch;
+        }
+        names.push_back(tok);
+        for (const std::string& fn : names) {
+          if (mtl_loaded.count(fn)) continue;
+          std::ifstream f(mtl_dir + "/" + fn, std::ios::binary);
+          if (!f) continue;                                     // a missing .mtl is a warning, not an error
           std::stringstream ss; ss << f.rdbuf();
           parse_mtl(ss.str(), m->materials, m->unknown, mat_by_name);
-        }  // a missing .mtl is a warning, not an error (tiny_obj_loader behaviour)
+          mtl_loaded.insert(fn);
+          break;
+        }
       }
     }
     // g / o / s / anything else: no effect on the flattened triangle list

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(_abi.LIB_PATH)
     for name in _header_symbols():
         assert hasattr(lib, name), f"librtcore.so does not export {name}"
-    assert lib.rt_abi_version() == 4
+    assert lib.rt_abi_version() == 5
 
 
 def test_no_torch_types_in_header():

@@ -234,3 +234,141 @@ def test_load_texture_and_bind_obj_surface(rt, tmp_path):
     assert bound == [("a.ppm", 0)]
     assert c.calls == [("surface",), ("texture", 0, (5, 7, 3)),
                        ("materials", [((1.0, 0.5, 0.25), 0), ((0.1, 0.2, 0.3), -1), ((0.9, 0.9, 0.9), 0)])]
+
+
+# ---- LoadMtl restated branch by branch: every expected value below is worked from the TEXT of tiny_obj_loader.h (no code of it
+# ---- was run: SURVEY §8c), the line numbers are those of /root/reference/tiny_obj_loader.h
+TRI = "v 0 0 0\nv 1 0 0\nv 0 1 0\n"
+
+
+def _mats(rt, mtl, obj=TRI + "f 1 2 3\n"):
+    return rt.parse_obj(obj, mtl).materials
+
+
+def test_mtl_default_diffuse_is_zero_without_kd_and_map_kd(rt):
+    """InitMaterial sets diffuse to 0 (:1588); nothing else touches it when the material has neither Kd nor map_Kd."""
+    (m,) = _mats(rt, "newmtl bare\nKa 0.25 0.5 0.75\nNs 8\n")
+    assert m["diffuse"] == (0.0, 0.0, 0.0) and m["ambient"] == (0.25, 0.5, 0.75) and m["shininess"] == 8.0
+    assert m["dissolve"] == 1.0 and m["ior"] == 1.0 and m["illum"] == 0 and m["map_Kd"] == ""      # :1593-1596
+
+
+def test_mtl_map_kd_sets_0_6_only_when_no_kd_came_before(rt):
+    """:2609-2625: `if (!has_kd) diffuse = 0.6` runs when the map_Kd LINE is parsed: a Kd line in front of it survives, a Kd
+    line behind it overwrites the 0.6 (:2432-2442)."""
+    a, b, c = _mats(rt, "newmtl only_map\nmap_Kd t.png\n"
+                        "newmtl map_then_kd\nmap_Kd t.png\nKd 0.125 0.25 0.5\n"
+                        "newmtl kd_then_map\nKd 0.125 0.25 0.5\nmap_Kd t.png\n")
+    assert a["diffuse"] == tuple(float(np.float32(0.6)) for _ in range(3))
+    assert b["diffuse"] == (0.125, 0.25, 0.5) and c["diffuse"] == (0.125, 0.25, 0.5)
+    assert a["map_Kd"] == b["map_Kd"] == c["map_Kd"] == "t.png"
+
+
+def test_mtl_texture_options_are_stripped_from_the_name(rt):
+    """ParseTextureNameAndOption (:1411-1528): options in front of the name are consumed into texture_option_t; the name is
+    the rest of the line from the first non-option token, blanks included."""
+    (m,) = _mats(rt, "newmtl m\nmap_Kd -s 2 2 1 -o 0.5 0 0 file name with spaces.png\n"
+                     "map_Bump -bm 0.25 -imfchan r -clamp on n.png\n"
+                     "refl -type cube_left -texres 256 -mm 0.5 2 -blendu off -blendv bogus -boost 3 -t 1 2 3 -colorspace sRGB r.hdr -s 9 9 9\n")
+    assert m["map_Kd"] == "file name with spaces.png"
+    o = m["map_Kd_opt"]
+    assert o["scale"] == (2.0, 2.0, 1.0) and o["origin_offset"] == (0.5, 0.0, 0.0) and o["imfchan"] == "m" and o["clamp"] == 0
+    assert m["map_Bump"] == "n.png"
+    b = m["map_Bump_opt"]
+    assert b["bump_multiplier"] == 0.25 and b["imfchan"] == "r" and b["clamp"] == 1 and b["scale"] == (1.0, 1.0, 1.0)
+    # options BEHIND the name are part of the name (:1509-1512 reads to the end of the line)
+    assert m["refl"] == "r.hdr -s 9 9 9"
+    r = m["refl_opt"]
+    assert r["type"] == 6 and r["texture_resolution"] == 256 and (r["brightness"], r["contrast"]) == (0.5, 2.0)
+    assert r["blendu"] == 0 and r["blendv"] == 1                         # parseOnOff: neither "on" nor "off" -> its default, true
+    assert r["sharpness"] == 3.0 and r["turbulence"] == (1.0, 2.0, 3.0) and r["colorspace"] == "sRGB" and r["scale"] == (1.0, 1.0, 1.0)
+    # defaults of InitTexOpt (:1530-1558) where a map has no line at all; the bump slot alone starts with imfchan 'l'
+    d = m["map_Ks_opt"]
+    assert m["map_Ks"] == "" and d["imfchan"] == "m" and d["texture_resolution"] == -1 and d["blendu"] == 1 and d["scale"] == (1.0, 1.0, 1.0)
+    assert _mats(rt, "newmtl m\nKd 1 1 1\n")[0]["map_Bump_opt"]["imfchan"] == "l"
+
+
+def test_mtl_options_without_a_name_leave_the_name_alone(rt):
+    """No filename token -> ParseTextureNameAndOption returns false and *texname keeps its value (:1519-1527); map_d first
+    stores the raw rest of the line (:2669), so there the options themselves stay as the name."""
+    (m,) = _mats(rt, "newmtl m\nmap_Kd first.png\nmap_Kd -clamp on\nmap_d -clamp on\n")
+    assert m["map_Kd"] == "first.png" and m["map_Kd_opt"]["clamp"] == 1
+    assert m["map_d"] == "-clamp on" and m["map_d_opt"]["clamp"] == 1
+    # a name that merely starts like an option is a name: IS_SPACE(token[2]) fails for "-old.png" (:1448)
+    assert _mats(rt, "newmtl m\nmap_Kd -old.png\n")[0]["map_Kd"] == "-old.png"
+
+
+def test_mtl_d_wins_against_tr(rt):
+    """:2506-2541: `Tr` sets dissolve = 1 - Tr unless a `d` line came before it in this material; a later `d` always overwrites."""
+    a, b, c = _mats(rt, "newmtl d_then_tr\nd 0.75\nTr 0.5\n" "newmtl tr_then_d\nTr 0.5\nd 0.75\n" "newmtl tr_only\nTr 0.25\n")
+    assert a["dissolve"] == 0.75 and b["dissolve"] == 0.75 and c["dissolve"] == 0.75
+    # parseReal's default is 0.0 for `d` too (:1124, :2509): an unparsable value is 0, not 1
+    assert _mats(rt, "newmtl m\nd x\n")[0]["dissolve"] == 0.0
+
+
+def test_usemtl_unknown_name_is_minus_one_and_names_are_one_word(rt):
+    """usemtl (:3200-3233): parseString = ONE word, looked up in material_map; not found -> material id -1 (and a warning
+    there).  newmtl (:2403-2414) takes one word as well; std::map::insert keeps the FIRST material of a repeated name."""
+    mtl = "newmtl red paint\nKd 1 0 0\nnewmtl blue\nKd 0 0 1\nnewmtl red\nKd 0.5 0 0\n"
+    obj = TRI + "usemtl red\nf 1 2 3\nusemtl nope\nf 1 2 3\nusemtl blue extra words\nf 1 2 3\nusemtlred\nf 1 2 3\nusemtl\nf 1 2 3\n"
+    m = rt.parse_obj(obj, mtl)
+    assert [x["name"] for x in m.materials] == ["red", "blue", "red"]
+    assert list(m.material_ids) == [0, -1, 1, 0, -1]            # "usemtlred": no blank is asked for behind the key (:3200)
+
+
+def test_mtl_without_newmtl_yields_the_default_material(rt):
+    """LoadMtl creates a default material anyway (:2328) and always flushes the last one, named or not (:2764-2767); lines in
+    front of the first newmtl land in that nameless material, which a first newmtl then discards (:2388)."""
+    (only,) = _mats(rt, "Kd 0.25 0.5 0.75\n")
+    assert only["name"] == "" and only["diffuse"] == (0.25, 0.5, 0.75)
+    (named,) = _mats(rt, "Kd 0.25 0.5 0.75\nnewmtl a\nKs 1 1 1\n")
+    assert named["name"] == "a" and named["diffuse"] == (0.0, 0.0, 0.0) and named["specular"] == (1.0, 1.0, 1.0)
+
+
+def test_mtl_pbr_and_remaining_fields(rt):
+    (m,) = _mats(rt, "newmtl m\nKs 0.1 0.2 0.3\nKt 0.4 0.5 0.6\nNi 1.45\nNs 96\nPr 0.5\nPm 0.25\nPs 0.125\nPc 0.75\nPcr 0.0625\n"
+                     "aniso 0.5\nanisor 0.25\nmap_Pr r.png\nmap_Pm m.png\nmap_Ps s.png\nmap_Ke e.png\nnorm n.png\nmap_Ka a.png\n"
+                     "map_Ns ns.png\ndisp d.png\nmap_Disp D.png\nTf 1 1 1\n")
+    f32 = lambda x: float(np.float32(x))
+    assert m["specular"] == (f32(0.1), f32(0.2), f32(0.3)) and m["transmittance"] == (1.0, 1.0, 1.0)       # Tf after Kt: same field (:2457)
+    assert m["ior"] == f32(1.45) and m["shininess"] == 96.0
+    assert (m["roughness"], m["metallic"], m["sheen"], m["clearcoat_thickness"], m["clearcoat_roughness"]) == (0.5, 0.25, 0.125, 0.75, 0.0625)
+    assert (m["anisotropy"], m["anisotropy_rotation"]) == (0.5, 0.25)
+    assert [m[k] for k in ("map_Pr", "map_Pm", "map_Ps", "map_Ke", "norm", "map_Ka", "map_Ns", "disp")] == \
+        ["r.png", "m.png", "s.png", "e.png", "n.png", "a.png", "ns.png", "D.png"]
+    assert m["unknown_parameter"] == {}
+
+
+def test_mtllib_takes_the_first_file_that_opens(rt, tmp_path):
+    """:3236-3303: the names on a mtllib line are split at ' ' ('\\' escapes), tried in order, the first that opens ends the search."""
+    (tmp_path / "b.mtl").write_text("newmtl fromb\nKd 0 1 0\n")
+    (tmp_path / "c.mtl").write_text("newmtl fromc\nKd 0 0 1\n")
+    (tmp_path / "with space.mtl").write_text("newmtl spaced\nKd 1 1 0\n")
+    (tmp_path / "o.obj").write_text("mtllib missing.mtl b.mtl c.mtl\nmtllib with\\ space.mtl\nmtllib b.mtl\n" + TRI + "usemtl fromb\nf 1 2 3\nusemtl fromc\nf 1 2 3\nusemtl spaced\nf 1 2 3\n")
+    m = rt.load_obj(tmp_path / "o.obj")
+    assert [x["name"] for x in m.materials] == ["fromb", "spaced"] and list(m.material_ids) == [0, -1, 1]
+
+
+def test_reference_mtl_files_parse_to_the_values_written_out_by_hand(rt):
+    """The reference's three MTL files (models/*.mtl, data fixtures copied by tests/golden/make_textures.py), expected values
+    read off their text with the rules above."""
+    def load(name):
+        return _mats(rt, open(os.path.join(GOLDEN, name)).read())
+    one = (1.0, 1.0, 1.0)
+    p85, p86 = load("plane_material.mtl")
+    for m, kd in ((p85, "Material_85_baseColor.jpg"), (p86, "Material_86_baseColor.png")):
+        # `Kd 1 1 1   # fallback ...`: parseReal3 reads three tokens, the rest of the line is never looked at (:2434-2441)
+        assert m["diffuse"] == one and m["emission"] == (0.0, 0.0, 0.0) and m["illum"] == 2
+        assert m["dissolve"] == 1.0                              # `d 1` then `Tr 0`: d wins
+        assert m["map_Kd"] == kd and m["map_Bump"] == "Material_85_normal.jpg"
+        # map_Pr / map_Pm ARE fields of material_t in this tinyobj version (:2705-2719) - the MTL's own comment, which expects
+        # them in unknown_parameter, describes an older one
+        assert m["map_Pr"] == m["map_Pm"] == "Material_85_metallicRoughness_metal.jpg" and m["unknown_parameter"] == {}
+    assert (p85["name"], p86["name"]) == ("Material_85", "Material_86")
+    d1, d2 = load("dragon_material.mtl")
+    assert d1["name"] == "MI_M_B_44_Qishilong_body02_Inst" and d2["name"] == "MI_M_B_44_Qishilong_body02_2_Inst"
+    assert d1["map_Kd"] == "MI_M_B_44_Qishilong_body02_Inst_diffuse.jpg" and d1["norm"] == "MI_M_B_44_Qishilong_body02_Inst_normal.jpg"
+    assert d2["map_Kd"] == "MI_M_B_44_Qishilong_body02_2_Inst_diffuse.jpg" and d2["norm"] == ""
+    for m in (d1, d2):
+        assert m["diffuse"] == one and m["dissolve"] == 1.0 and m["illum"] == 2 and (m["roughness"], m["metallic"]) == (0.0, 0.0)
+    (q,) = load("2Dplane_material.mtl")
+    assert q["name"] == "TexturedPlaneMaterial" and q["map_Kd"] == "texture.png" and q["diffuse"] == one and q["dissolve"] == 1.0
