@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 5   /* 5: rt_material carries all of material_t + texture options;
+#define RT_ABI_VERSION 5   /* 5: rt_material carries all of material_t + texture options, rt_batch_stats;
                               2: rt_render_stats.pixels_traced, rt_render_device_noalloc, cache-file trailer; 3: rt_render_batch_device; 4: rt_frame_rect, rt_assemble_device_on, RT_MAX_BATCH 32 */
 
 enum {
@@ -51,6 +51,9 @@ int         rt_create(rt_ctx** out, const char* backend, const int* device_ids, 
 void        rt_destroy(rt_ctx* ctx);
 const char* rt_last_error(const rt_ctx* ctx);
 int         rt_abi_version(void);
+/* Diagnostic: how many hipMalloc / hipFree calls this library has made in the process so far (all contexts).  Unchanged
+ * across a call = that call allocated and freed nothing; tests/test_zz_no_alloc.py holds rt_render_device_noalloc to it. */
+uint64_t    rt_debug_device_allocations(void);
 
 /* ------------------------------------------------------------------ scene input (host side, no GPU needed) */
 /* OBJ/MTL ingest with tiny_obj_loader v2.0.0 semantics (reference: /tiny_obj_loader.h:638,
@@ -286,13 +289,19 @@ int rt_render_device_noalloc(rt_ctx* ctx, const float uniforms[44], const rt_ren
  * Per frame of a 32-frame batch against per-frame launches (one MI355X): 4K 0.44 -> 0.26 ms, 1080p 0.26 -> 0.064 ms.
  * (What differs between the frames - uniforms, output pointers - is copied into device memory ahead of the pipeline: the
  * uniforms and pointer arrays are free again when the call returns.)
- * RT_MODE_PRIMARY / SHADOW / PT only (PT runs one lane per pixel); no statistics (RT_FLAG_COUNT_WORK is refused);
+ * RT_MODE_PRIMARY / SHADOW / PT only (PT runs one lane per pixel); with RT_FLAG_COUNT_WORK every frame's counters are kept
+ * (rt_batch_stats below; the counting instantiation is a few per cent slower, as for single frames); frames whose 44 uniforms
+ * are byte-identical share one cull / compaction result (each is still traced and written in full);
  * asynchronous on rt_stream() - or, with rt_set_frames_in_flight(n >= 2), on the frame streams under the ordering rules
  * given there (a batch counts as one frame: the tail of batch i overlaps the head of batch i+1); the scheduling hints
  * left behind are those of the last frame, and a batch whose views differ is not ordered by hints at all. */
 #define RT_MAX_BATCH 32
 int rt_render_batch_device(rt_ctx* ctx, uint32_t n_frames, const float* uniforms /* [n_frames][44] */, const rt_render_opts* opts,
                            void* const* d_rgba8, void* const* d_hit_tri, void* const* d_hit_t);
+/* The counters of the last rt_render_batch_device call that carried RT_FLAG_COUNT_WORK: one rt_render_stats per frame, each
+ * equal to what rt_render_device(uniforms + 44 f, ...) reports for that frame (ms_kernel / ms_traverse are 0: a batch is one
+ * launch; rt_profile_begin/end time it).  n_frames must be that batch's frame count.  Synchronises. */
+int rt_batch_stats(rt_ctx* ctx, uint32_t n_frames, rt_render_stats* out /* [n_frames] */);
 /* De-interleave `world` packed stripe buffers (concatenated rank-major, each
  * rows_per_rank x width x elem_bytes) into a full image; all pointers are device memory. */
 int rt_deinterleave_device(rt_ctx* ctx, const void* d_packed, void* d_image, uint32_t width, uint32_t height,

@@ -201,6 +201,11 @@ def render_opts_for_mode(mode, **overrides):
     return o
 
 
+def device_allocations():
+    """hipMalloc + hipFree calls the library has made in this process (rt_debug_device_allocations)."""
+    return int(_L.rt_debug_device_allocations())
+
+
 def packed_rows(height, stripe_rows, rank, world):
     return int(_L.rt_packed_rows(height, stripe_rows, rank, world))
 
@@ -378,6 +383,12 @@ class Context:
                 raise ValueError("one device address per frame")
             return (C.c_void_p * n)(*[C.c_void_p(int(x) or None) for x in a])
         self._chk(_L.rt_render_batch_device(self._h, n, _vp(U), C.byref(opts), ptrs(d_rgba8), ptrs(d_hit_tri), ptrs(d_hit_t)))
+
+    def batch_stats(self, n_frames):
+        """Per-frame counters of the last render_batch_device call made with FLAG_COUNT_WORK (rt_batch_stats); synchronises."""
+        arr = (_abi.RenderStats * n_frames)()
+        self._chk(_L.rt_batch_stats(self._h, n_frames, arr))
+        return [a.as_dict() for a in arr]
 
     def deinterleave_device(self, d_packed, d_image, width, height, elem_bytes, stripe_rows, world, rows_per_rank, stream=None):
         """stream: a hipStream_t (integer) of this GPU to launch on instead of the context stream."""

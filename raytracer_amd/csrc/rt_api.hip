@@ -13,8 +13,10 @@
 
 #include "rt_internal.h"
 
+#include <atomic>
 namespace {
 std::string g_create_error;
+std::atomic<unsigned long long> g_dev_alloc_calls{0};   // hipMalloc + hipFree calls of this library (every one goes through DevBuf)
 
 template <typename T>
 struct DevBuf {
@@ -22,13 +24,14 @@ struct DevBuf {
   size_t n = 0;
   hipError_t ensure(size_t count) {
     if (count <= n && p) return hipSuccess;
-    if (p) { (void)hipFree(p); p = nullptr; n = 0; }
+    if (p) { g_dev_alloc_calls += 1; (void)hipFree(p); p = nullptr; n = 0; }
     if (count == 0) return hipSuccess;
+    g_dev_alloc_calls += 1;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
     if (e == hipSuccess) n = count;
     return e;
   }
-  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  void release() { if (p) { g_dev_alloc_calls += 1; (void)hipFree(p); } p = nullptr; n = 0; }
 };
 }  // namespace
 
@@ -128,6 +131,9 @@ struct rt_ctx {
   DevBuf<float4> pt_recs[MAX_FIF];             // PT split records (rt_trace.hip), per frame slot
   DevBuf<float> pt_terms[MAX_FIF];
   DevBuf<unsigned long long> r_stats[MAX_FIF];
+  DevBuf<unsigned long long> r_bstats[MAX_FIF];   // a counted batch: [RT_MAX_BATCH][9] totals, then [n][resident waves][8] per-wave partials
+  int bstats_slot = -1;                           // frame slot + frame count of the last batch rendered with RT_FLAG_COUNT_WORK (rt_batch_stats)
+  uint32_t bstats_n = 0;
   // frames in flight (rt_set_frames_in_flight): asynchronous frames alternate between two frame streams so that the
   // tail of frame i (few waves left, latency-bound) overlaps the head of frame i+1
   DevBuf<uint8_t> pix_class;                   // frame-coherent scheduling hints (rt_trace.hip), shared by the frame slots
@@ -178,6 +184,16 @@ int join_frames(rt_ctx* ctx) {
   return RT_OK;
 }
 #define JOIN_FRAMES() do { const int jrc_ = join_frames(ctx); if (jrc_ != RT_OK) return jrc_; } while (0)
+
+// A frame (or batch) that rotates over the frame streams takes its slot's issue number before work that can still fail
+// (scratch growth, limits): unless the pipeline was really queued (done = true), the number and the slot's previous issue
+// number come back, so rt_frames_join's keep_latest accounting and the slot rotation stay exact.
+struct SlotTicket {
+  rt_ctx* c; int slot = 0; uint32_t old_seq = 0; bool taken = false, done = false;
+  explicit SlotTicket(rt_ctx* ctx) : c(ctx) {}
+  void take(int k) { slot = k; old_seq = c->f_seq[k]; c->f_seq[k] = c->f_count++; taken = true; }
+  ~SlotTicket() { if (taken && !done) { c->f_count -= 1; c->f_seq[slot] = old_seq; } }
+};
 
 // limits of the two node-record encodings
 int check_encoding_limits(rt_ctx* ctx, const char* who, uint64_t n_nodes, uint64_t n_tri) {
@@ -231,6 +247,7 @@ int finish_bvh(rt_ctx* ctx, bool packed_by_refit = false) {
 
 // ================================================================ context
 extern "C" int rt_abi_version(void) { return RT_ABI_VERSION; }
+extern "C" uint64_t rt_debug_device_allocations(void) { return g_dev_alloc_calls.load(); }
 
 extern "C" int rt_create(rt_ctx** out, const char* backend, const int* device_ids, int n_devices) {
   if (!out) return RT_ERR_INVALID;
@@ -278,7 +295,7 @@ extern "C" void rt_destroy(rt_ctx* ctx) {
   for (auto& t : ctx->texels) t.release();
   ctx->tex_table.release();
   for (int k = 0; k < rt_ctx::MAX_FIF; ++k) {
-    ctx->r_tile_counter[k].release(); ctx->r_list[k].release(); ctx->r_frames[k].release(); ctx->r_stats[k].release(); ctx->pt_recs[k].release(); ctx->pt_terms[k].release();
+    ctx->r_tile_counter[k].release(); ctx->r_list[k].release(); ctx->r_frames[k].release(); ctx->r_stats[k].release(); ctx->r_bstats[k].release(); ctx->pt_recs[k].release(); ctx->pt_terms[k].release();
     if (ctx->fstream[k]) { (void)hipStreamSynchronize(ctx->fstream[k]); (void)hipStreamDestroy(ctx->fstream[k]); }
     if (ctx->f_done[k]) (void)hipEventDestroy(ctx->f_done[k]);
   }
@@ -574,20 +591,27 @@ extern "C" int rt_load_bvh(rt_ctx* ctx, const char* path) {
   std::fclose(f);
   if (r != (size_t)sz) return ctx->fail(RT_ERR_IO, "short read");
   size_t T = 0, N = 0;
+  int file_encoding = 0;
   if (sz >= 16 + 32 + 96) {                          // trailer {magic, N, T, encoding} consistent with the file size?
     uint32_t tr[4];
     std::memcpy(tr, buf.data() + buf.size() - 4, sizeof(tr));
     if (tr[0] == BVH_FILE_MAGIC && (tr[3] == RT_NODES_V1 || tr[3] == RT_NODES_V2) && tr[1] > 0 && tr[2] > 0 &&
         32ull * tr[1] + 96ull * tr[2] + 16ull == (unsigned long long)sz) {
       N = tr[1]; T = tr[2];
-      ctx->node_encoding = (int)tr[3];               // the file says how its slots A / B are encoded
+      file_encoding = (int)tr[3];                    // the file says how its slots A / B are encoded
     }
   }
   if (N == 0) {                                      // header-less: 32 B x (2T-1) + 96 B x T = 160 T - 32, encoding = the context's setting
     if ((sz + 32) % 160 != 0) return ctx->fail(RT_ERR_IO, "not a BVH cache file (no trailer, and the size is not 160*T-32 bytes)");
     T = (size_t)(sz + 32) / 160; N = 2 * T - 1;
   }
-  return rt_set_bvh(ctx, buf.data(), (uint32_t)N, buf.data() + 8 * N, buf.data() + 8 * N + 12 * T, (uint32_t)T);
+  // a trailer's encoding becomes the context's setting only if the tree is accepted: a rejected / corrupt file must not
+  // change how the next rt_build_lbvh encodes its records
+  const int old_encoding = ctx->node_encoding;
+  if (file_encoding) ctx->node_encoding = file_encoding;
+  const int rc = rt_set_bvh(ctx, buf.data(), (uint32_t)N, buf.data() + 8 * N, buf.data() + 8 * N + 12 * T, (uint32_t)T);
+  if (rc != RT_OK) ctx->node_encoding = old_encoding;
+  return rc;
 }
 
 // ================================================================ multi-GPU plumbing
@@ -946,9 +970,10 @@ int render_frame(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* op
   const bool overlap = !noalloc && ctx->frames_in_flight >= 2 && out == nullptr;
   int slot = 0;
   hipStream_t s = ctx->stream;
+  SlotTicket ticket(ctx);
   if (overlap) {
     slot = (int)(ctx->f_count % (uint32_t)ctx->frames_in_flight);
-    ctx->f_seq[slot] = ctx->f_count++;
+    ticket.take(slot);
     s = ctx->fstream[slot];
     HIPCHK(hipEventRecord(ctx->f_main, ctx->stream));
     HIPCHK(hipStreamWaitEvent(s, ctx->f_main, 0));
@@ -1035,6 +1060,7 @@ int render_frame(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* op
   if (overlap) {
     HIPCHK(hipEventRecord(ctx->f_done[slot], s));
     ctx->f_pending[slot] = true;
+    ticket.done = true;
   }
   if (out) {
     unsigned long long st[8];
@@ -1068,7 +1094,6 @@ int render_batch(rt_ctx* ctx, uint32_t n_frames, const float* uniforms, const rt
   int rc = check_opts(ctx, opts);
   if (rc != RT_OK) return rc;
   if (opts->mode > RT_MODE_PT) return ctx->fail(RT_ERR_INVALID, "rt_render_batch_device: RT_MODE_PRIMARY / SHADOW / PT only");
-  if (opts->flags & RT_FLAG_COUNT_WORK) return ctx->fail(RT_ERR_INVALID, "rt_render_batch_device keeps no statistics: RT_FLAG_COUNT_WORK is not defined for it");
   const float fw = uniforms[36], fh = uniforms[37];
   if (!(fw >= 1.0f) || !(fh >= 1.0f) || fw > 65536.0f || fh > 65536.0f) return ctx->fail(RT_ERR_INVALID, "resolution out of range");
   RtBatch bt;
@@ -1084,6 +1109,11 @@ int render_batch(rt_ctx* ctx, uint32_t n_frames, const float* uniforms, const rt
       return ctx->fail(RT_ERR_INVALID, "output pointers must be 4-byte aligned");
     std::memcpy(recs[f].U, U, sizeof(float) * RT_U_FLOATS);
     recs[f].rgba8 = static_cast<uint8_t*>(o[0]); recs[f].hit_tri = static_cast<uint32_t*>(o[1]); recs[f].hit_t = static_cast<float*>(o[2]);
+    // frames whose 44 uniforms are byte-identical to an earlier frame's share that frame's cull masks and pixel list: one
+    // k_scan / k_compact per distinct view (every frame is still traced and written in full)
+    recs[f].src = f;
+    for (uint32_t g = 0; g < f; ++g)
+      if (std::memcmp(uniforms + 44 * (size_t)g, U, sizeof(float) * 44) == 0) { recs[f].src = g; break; }
   }
   DeviceGuard g(ctx->device);
   RtRenderParams p;
@@ -1106,11 +1136,14 @@ int render_batch(rt_ctx* ctx, uint32_t n_frames, const float* uniforms, const rt
   // Pipelines in flight, as render_frame: with rt_set_frames_in_flight(n >= 2) batches rotate over the n frame streams (own
   // scratch each), so the cull / compaction passes and the head of batch i+1 run beside the tail of batch i.
   const bool overlap = ctx->frames_in_flight >= 2;
+  const size_t list_words = ((size_t)p.local_rows * p.width + 63u) & ~(size_t)63u;
+  if (list_words * n_frames > 0xFFFFFFFFull) return ctx->fail(RT_ERR_LIMIT, "rt_render_batch_device: the batch's pixel lists exceed 2^32 entries");
   int slot = 0;
   hipStream_t s = ctx->stream;
+  SlotTicket ticket(ctx);
   if (overlap) {
     slot = (int)(ctx->f_count % (uint32_t)ctx->frames_in_flight);
-    ctx->f_seq[slot] = ctx->f_count++;
+    ticket.take(slot);
     s = ctx->fstream[slot];
     HIPCHK(hipEventRecord(ctx->f_main, ctx->stream));
     HIPCHK(hipStreamWaitEvent(s, ctx->f_main, 0));
@@ -1118,12 +1151,10 @@ int render_batch(rt_ctx* ctx, uint32_t n_frames, const float* uniforms, const rt
     JOIN_FRAMES();
   }
   p.blocks_per_cu_cap = overlap ? 2u : 0u;
-  const size_t list_words = ((size_t)p.local_rows * p.width + 63u) & ~(size_t)63u;
   bt.mask_stride = rt_n_class() * p.n_tiles;
   bt.bt_stride = rt_n_class() * cull_blocks;
   bt.list_stride = (uint32_t)list_words;
   bt.lc_stride = RT_LC_WORDS;
-  if (list_words * n_frames > 0xFFFFFFFFull) return ctx->fail(RT_ERR_LIMIT, "rt_render_batch_device: the batch's pixel lists exceed 2^32 entries");
   const size_t tc_words = (size_t)rt_shard_words() + (size_t)RT_LC_WORDS * n_frames + (size_t)bt.bt_stride * n_frames;
   const size_t st_words = 8 + 32 + (size_t)bt.mask_stride * n_frames;
   HIPCHK(ctx->r_tile_counter[slot].ensure(tc_words));
@@ -1131,6 +1162,8 @@ int render_batch(rt_ctx* ctx, uint32_t n_frames, const float* uniforms, const rt
   HIPCHK(ctx->r_stats[slot].ensure(st_words));
   if (ctx->r_stats[slot].p != st_before) ctx->class_partial_reset[slot] = true;
   HIPCHK(ctx->r_list[slot].ensure(list_words * n_frames));
+  const bool count_work = (opts->flags & RT_FLAG_COUNT_WORK) != 0;
+  if (count_work) HIPCHK(ctx->r_bstats[slot].ensure((size_t)RT_MAX_BATCH * 9 + (size_t)n_frames * rt_render_grid(ctx->n_cu) * 4 * 8));
   uint32_t* sc_tc = ctx->r_tile_counter[slot].p;
   unsigned long long* sc_st = ctx->r_stats[slot].p;
   p.shard_stride = rt_shard_stride();
@@ -1142,6 +1175,7 @@ int render_batch(rt_ctx* ctx, uint32_t n_frames, const float* uniforms, const rt
   p.stats = sc_st;
   p.class_hist = reinterpret_cast<uint32_t*>(sc_st + 8);        // where render_frame keeps it: single frames and batches share the history
   p.masks = sc_st + 8 + 32;
+  if (count_work) { p.stats = ctx->r_bstats[slot].p; p.stats_partial = ctx->r_bstats[slot].p + (size_t)RT_MAX_BATCH * 9; }
   if (ctx->coherent_scheduling) {
     bool moved = std::memcmp(ctx->last_uniforms, uniforms, sizeof(float) * 44) != 0;
     for (uint32_t f = 1; f < n_frames; ++f) moved = moved || std::memcmp(uniforms, uniforms + 44 * (size_t)f, sizeof(float) * 44) != 0;
@@ -1167,12 +1201,14 @@ int render_batch(rt_ctx* ctx, uint32_t n_frames, const float* uniforms, const rt
   hipEvent_t* E = nullptr;   // {batch begin, k_render begin, k_render end, batch end}: rt_profile_end reports per batch
   if (ctx->prof_on) { E = &ctx->prof_ev[4 * (size_t)(ctx->prof_n % rt_ctx::PROF_RING)]; ctx->prof_n += 1; }
   if (E) HIPCHK(hipEventRecord(E[0], s));
-  rt_launch_render_batch(p, bt, opts->layout, ctx->n_cu, s, E ? E[1] : nullptr, E ? E[2] : nullptr);
+  rt_launch_render_batch(p, bt, opts->layout, count_work, ctx->n_cu, s, E ? E[1] : nullptr, E ? E[2] : nullptr);
   HIPCHK(hipGetLastError());
+  if (count_work) { ctx->bstats_slot = slot; ctx->bstats_n = n_frames; }
   if (E) HIPCHK(hipEventRecord(E[3], s));
   if (overlap) {
     HIPCHK(hipEventRecord(ctx->f_done[slot], s));
     ctx->f_pending[slot] = true;
+    ticket.done = true;
   }
   return RT_OK;
 }
@@ -1193,6 +1229,27 @@ extern "C" int rt_render_batch_device(rt_ctx* ctx, uint32_t n_frames, const floa
                                       void* const* d_rgba8, void* const* d_hit_tri, void* const* d_hit_t) {
   if (!ctx) return RT_ERR_INVALID;
   return render_batch(ctx, n_frames, uniforms, opts, d_rgba8, d_hit_tri, d_hit_t);
+}
+
+// Counters of the last batch that was rendered with RT_FLAG_COUNT_WORK, one rt_render_stats per frame (synchronises).
+extern "C" int rt_batch_stats(rt_ctx* ctx, uint32_t n_frames, rt_render_stats* out) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (!out) return ctx->fail(RT_ERR_INVALID, "rt_batch_stats: NULL output");
+  if (ctx->bstats_slot < 0 || ctx->bstats_n == 0) return ctx->fail(RT_ERR_INVALID, "rt_batch_stats: no batch has been rendered with RT_FLAG_COUNT_WORK");
+  if (n_frames != ctx->bstats_n) return ctx->fail(RT_ERR_INVALID, "rt_batch_stats: the last counted batch had " + std::to_string(ctx->bstats_n) + " frames");
+  DeviceGuard g(ctx->device);
+  JOIN_FRAMES();
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  unsigned long long st[RT_MAX_BATCH * 9];
+  HIPCHK(hipMemcpy(st, ctx->r_bstats[ctx->bstats_slot].p, sizeof(unsigned long long) * 9 * n_frames, hipMemcpyDeviceToHost));
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    const unsigned long long* v = st + 9 * (size_t)f;
+    rt_render_stats& o = out[f];
+    std::memset(&o, 0, sizeof(o));
+    o.rays_primary = v[0]; o.rays_shadow = v[1]; o.rays_bounce = v[2]; o.box_tests = v[3]; o.tri_tests = v[4]; o.hit_updates = v[5];
+    o.pixels = v[6]; o.stack_drops = v[7]; o.pixels_traced = v[8];
+  }
+  return RT_OK;
 }
 
 extern "C" int rt_set_coherent_scheduling(rt_ctx* ctx, int on) {

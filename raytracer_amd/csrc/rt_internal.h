@@ -106,6 +106,8 @@ struct RtFrameRec {
   uint32_t* hit_tri;
   float*    hit_t;
   int       cull[4];         // x0, x1, y0, y1
+  uint32_t  src;             // index of the first frame of the batch with the same 44 uniforms (its own index unless a duplicate view):
+  uint32_t  pad_;            //   duplicates use that frame's tile masks and pixel list
 };
 constexpr int RT_FRAMES_PER_PUT = 16;
 struct RtFrameChunk { RtFrameRec r[RT_FRAMES_PER_PUT]; };
@@ -180,7 +182,8 @@ uint32_t rt_shard_stride();
 void rt_launch_render(const RtRenderParams& p, int layout, bool count_work, bool want_stats, int n_cu, hipStream_t s,
                       hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 // the same pipeline over bt.n frames (no stats, no PT split, compute.wgsl modes only)
-void rt_launch_render_batch(const RtRenderParams& p, const RtBatch& bt, int layout, int n_cu, hipStream_t s,
+// count_work: p.stats_partial = [bt.n][resident waves][8] u64 (zeroed here), p.stats = [bt.n][9] u64 totals (8 counters + pixels traced)
+void rt_launch_render_batch(const RtRenderParams& p, const RtBatch& bt, int layout, bool count_work, int n_cu, hipStream_t s,
                             hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 void rt_launch_put_frames(const RtFrameRec* host_recs, uint32_t n, RtFrameRec* d_frames, hipStream_t s);
 // BVH-order surface records: record i <- input triangle order[i]

@@ -673,6 +673,39 @@ RT_DEV void flush_stats(const RtRenderParams& p, int lane, const RayCount& R, co
   }
 }
 
+// A batch with RT_FLAG_COUNT_WORK: a wave's counters belong to the frame of the chunk it is working on; when the next chunk is
+// another frame's (and at the end) the wave adds them to ITS slot of that frame, stats_partial[frame][wave of the grid][8] -
+// a slot has one writer, so plain read-modify-write, no atomics - and starts from zero again.
+RT_DEV void flush_batch_stats(const RtRenderParams& p, uint32_t frame, int lane, RayCount& R, Work& W, uint32_t& pixels) {
+  const uint32_t c[8] = {R.primary, R.shadow, R.bounce, W.box, W.tri, W.hit, pixels, W.drops};
+  const size_t slot = ((size_t)frame * (gridDim.x * (TBLK / 64)) + blockIdx.x * (TBLK / 64) + (threadIdx.x >> 6)) * 8;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const uint32_t s = wave_sum_u32(c[k]);
+    if (lane == 0 && s) p.stats_partial[slot + k] += s;
+  }
+  R.primary = R.shadow = R.bounce = 0; W.box = W.tri = W.hit = W.drops = 0; pixels = 0;
+}
+// grid.x = frame: stats[frame][k] = sum over the frame's wave slots + the pixels k_cull disposed of (as k_stats_final)
+__global__ void k_stats_final_batch(const RtRenderParams p, const RtBatch bt, uint32_t n_slots, uint32_t n_inside, int count_work) {
+  __shared__ unsigned long long s_sum[8][32];
+  const uint32_t f = blockIdx.x;
+  const int k = threadIdx.x & 7, part = threadIdx.x >> 3;
+  unsigned long long t = 0;
+  for (uint32_t b = part; b < n_slots; b += 32) t += p.stats_partial[((size_t)f * n_slots + b) * 8 + k];
+  s_sum[k][part] = t;
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    unsigned long long tot = 0;
+    for (int i = 0; i < 32; ++i) tot += s_sum[threadIdx.x][i];
+    const uint32_t listed = p.list_count[(size_t)bt.frames[f].src * bt.lc_stride];
+    const unsigned long long culled = (unsigned long long)n_inside - (unsigned long long)listed;
+    if (threadIdx.x == 0 || threadIdx.x == 6 || (threadIdx.x == 3 && count_work)) tot += culled;
+    p.stats[(size_t)f * 9 + threadIdx.x] = tot;
+    if (threadIdx.x == 0) p.stats[(size_t)f * 9 + 8] = listed;       // pixels_traced
+  }
+}
+
 // stats[k] = sum of the phase-B block partials; pixels culled in phase A never reach phase B:
 // each of them is one primary ray, one root-box test, one pixel.
 __global__ void k_stats_final(const RtRenderParams p, uint32_t n_blocks, uint32_t n_inside, int count_work) {
@@ -725,6 +758,7 @@ static int shard_stride_words() { return SHARD_STRIDE; }
 struct FrameView {
   const float* U; uint8_t* rgba8; uint32_t* hit_tri; float* hit_t; int cull_x0, cull_x1, cull_y0, cull_y1;
   unsigned long long* masks; uint32_t* block_total; uint32_t* list; uint32_t* list_count;
+  bool dup;                // a batch frame whose 44 uniforms equal an earlier frame's: it shares that frame's masks / list (k_cull still writes ITS culled pixels)
 };
 template <bool BATCH, typename B>
 RT_DEV FrameView frame_view(const RtRenderParams& p, const B& bt, uint32_t f) {
@@ -733,9 +767,12 @@ RT_DEV FrameView frame_view(const RtRenderParams& p, const B& bt, uint32_t f) {
     const RtFrameRec& r = bt.frames[f];                    // f is wave-uniform: scalar loads
     v.U = r.U; v.rgba8 = r.rgba8; v.hit_tri = r.hit_tri; v.hit_t = r.hit_t;
     v.cull_x0 = r.cull[0]; v.cull_x1 = r.cull[1]; v.cull_y0 = r.cull[2]; v.cull_y1 = r.cull[3];
-    v.masks = p.masks + (size_t)f * bt.mask_stride; v.block_total = p.block_total + (size_t)f * bt.bt_stride;
-    v.list = p.list + (size_t)f * bt.list_stride; v.list_count = p.list_count + (size_t)f * bt.lc_stride;
+    const uint32_t g = r.src;                              // the frame whose cull / compaction result this one uses (itself unless a duplicate view)
+    v.masks = p.masks + (size_t)g * bt.mask_stride; v.block_total = p.block_total + (size_t)g * bt.bt_stride;
+    v.list = p.list + (size_t)g * bt.list_stride; v.list_count = p.list_count + (size_t)g * bt.lc_stride;
+    v.dup = g != f;
   } else {
+    v.dup = false;
     v.U = p.U; v.rgba8 = p.rgba8; v.hit_tri = p.hit_tri; v.hit_t = p.hit_t;
     v.cull_x0 = p.cull_x0; v.cull_x1 = p.cull_x1; v.cull_y0 = p.cull_y0; v.cull_y1 = p.cull_y1;
     v.masks = p.masks; v.block_total = p.block_total; v.list = p.list; v.list_count = p.list_count;
@@ -865,6 +902,7 @@ __global__ __launch_bounds__(TBLK) void k_cull(const RtRenderParams p, const B b
   for (int c = w; c < N_CLASS; c += TBLK / 64) {                 // lane = tile: masks out, per-class totals of the block
     const uint32_t tile = blockIdx.x * CULL_TPB + (uint32_t)lane;
     const unsigned long long m = s_m[c][lane];
+    if (fv.dup) continue;                                        // the earlier frame of this view writes the (identical) masks and totals
     if (tile < p.n_tiles) fv.masks[(size_t)tile * N_CLASS + c] = m;
     const uint32_t tot = wave_sum_u32((uint32_t)__popcll(m));
     if (lane == 0) fv.block_total[(size_t)blockIdx.x * N_CLASS + c] = tot;
@@ -878,6 +916,7 @@ __global__ __launch_bounds__(TBLK) void k_cull(const RtRenderParams p, const B b
 template <bool BATCH, typename B>
 __global__ __launch_bounds__(TBLK) void k_scan(const RtRenderParams p, const B bt) {
   const FrameView fv = frame_view<BATCH>(p, bt, BATCH ? blockIdx.x : 0u);
+  if (fv.dup) return;                                            // (block-uniform) one scan per distinct view
   __shared__ uint32_t s_wave[TBLK / 64][N_CLASS];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint32_t n_blocks = (p.n_tiles + CULL_TPB - 1) / CULL_TPB;      // = rt_cull_blocks(n_tiles), the grid of k_cull / k_compact
@@ -927,6 +966,7 @@ __global__ __launch_bounds__(TBLK) void k_scan(const RtRenderParams p, const B b
 template <bool BATCH, typename B>
 __global__ __launch_bounds__(TBLK) void k_compact(const RtRenderParams p, const B bt) {
   const FrameView fv = frame_view<BATCH>(p, bt, BATCH ? blockIdx.y : 0u);
+  if (fv.dup) return;                                            // (block-uniform) one pixel list per distinct view
   __shared__ uint32_t s_pref[N_CLASS][CULL_TPB];
   __shared__ uint32_t s_txy[CULL_TPB];
   __shared__ unsigned long long s_mask[N_CLASS][CULL_TPB];   // the block's masks, read from HBM once (the rounds below took one dependent load each)
@@ -1055,6 +1095,7 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p, const B
   Work W; W.box = W.tri = W.hit = W.drops = 0;
   RayCount R; R.primary = R.shadow = R.bounce = 0;
   uint32_t pixels = 0;
+  uint32_t cur_frame = 0xFFFFFFFFu;                      // BATCH && COUNT: the frame the counters above belong to
   uint32_t class_thr[N_CLASS];                           // class_thr[c], c >= 2: steps from which a pixel is of class c (k_compact)
 #pragma unroll
   for (int c = 2; c < N_CLASS; ++c) class_thr[c] = p.pix_class ? p.list_count[c] : 0xFFFFFFFFu;
@@ -1080,7 +1121,7 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p, const B
       if (run < n_seg) {
         seg_frame[r] = run % bt.n;
         const uint32_t c = (uint32_t)(N_CLASS - 1) - run / bt.n;                        // hottest class first, cheap / unknown (0) last
-        const uint32_t* lc = p.list_count + (size_t)seg_frame[r] * bt.lc_stride;
+        const uint32_t* lc = p.list_count + (size_t)bt.frames[seg_frame[r]].src * bt.lc_stride;
         seg_start[r] = lc[8 + c]; seg_count[r] = lc[16 + c];
         my_chunks = (seg_count[r] + 63u) / 64u;
       }
@@ -1113,6 +1154,7 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p, const B
       FrameView fv = frame_view<false>(p, bt, 0u);
       uint32_t li, li_end;
       bool last_frame = true;
+      uint32_t batch_frame = 0;
       if constexpr (!BATCH) { li = chunk * 64u + (uint32_t)lane; li_end = n_list; }
       else {
         // the last run that starts at or before this chunk (empty runs never match); chunk is wave-uniform, so are the branches
@@ -1129,6 +1171,11 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p, const B
         li = start + (chunk - first) * 64u + (uint32_t)lane; li_end = start + cnt;
         time_h = (float)hash_u32(sat_u32(fv.U[38]));
         last_frame = f + 1u == bt.n;
+        batch_frame = f;
+      }
+      if constexpr (BATCH && COUNT) {                       // counters are per frame: hand over what the previous chunk's frame collected
+        if (cur_frame != 0xFFFFFFFFu && cur_frame != batch_frame) flush_batch_stats(p, cur_frame, lane, R, W, pixels);
+        cur_frame = batch_frame;
       }
       PtRec rec;
       bool rec_hit = false;
@@ -1176,7 +1223,8 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p, const B
     t[0] = tl_start; t[1] = tl_last; t[2] = wall_clock64(); t[3] = tl_chunks;
   }
 #endif
-  if constexpr (!BATCH) flush_stats<COUNT>(p, lane, R, W, pixels);     // a batch keeps no statistics
+  if constexpr (!BATCH) flush_stats<COUNT>(p, lane, R, W, pixels);
+  else if constexpr (COUNT) { if (cur_frame != 0xFFFFFFFFu) flush_batch_stats(p, cur_frame, lane, R, W, pixels); }   // a batch keeps statistics only when asked to count
   if (p.pix_class) {                                     // 64 bins, one atomic per non-empty bin and block, spread over the launch's tail
     __syncthreads();
     if (threadIdx.x < 64 && s_hist[threadIdx.x]) atomicAdd(&p.class_hist[threadIdx.x], s_hist[threadIdx.x]);
@@ -1478,11 +1526,11 @@ void rt_launch_render(const RtRenderParams& p_in, int layout, bool count_work, b
 // A batch: the frames' cull / scan / compact passes as one grid dimension of three launches, then ONE persistent k_render over all
 // the frames' lists (rt_render_batch_device).  p carries what the frames share (tree, geometry of the image, scratch
 // bases); bt what differs.  No stats, no PT split.
-void rt_launch_render_batch(const RtRenderParams& p_in, const RtBatch& bt, int layout, int n_cu, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+void rt_launch_render_batch(const RtRenderParams& p_in, const RtBatch& bt, int layout, bool count_work, int n_cu, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
   RtRenderParams p = p_in;
   RtBatch batch = bt;
   const dim3 b(TBLK), gc(rt_cull_blocks(p.n_tiles), bt.n);
-  const void* kernel = render_kernel(layout, false, p.tri_uv != nullptr, KIND_PIXEL, true);
+  const void* kernel = render_kernel(layout, count_work, p.tri_uv != nullptr, KIND_PIXEL, true);
   p.render_blocks = resident_grid(n_cu, p.max_stack, kernel);
   if (p.blocks_per_cu_cap && !getenv("RTCORE_BLOCKS_PER_CU")) p.render_blocks = std::min(p.render_blocks, (uint32_t)n_cu * p.blocks_per_cu_cap);   // pipelines in flight share the CUs
   hipLaunchKernelGGL((k_cull<true, RtBatch>), gc, b, 0, s, p, batch);
@@ -1491,8 +1539,10 @@ void rt_launch_render_batch(const RtRenderParams& p_in, const RtBatch& bt, int l
   const size_t lds = (size_t)p.max_stack * TBLK * (sizeof(uint32_t) + sizeof(float));
   if (ev0) (void)hipEventRecord(ev0, s);
   void* args[2] = {&p, &batch};
+  if (count_work) (void)hipMemsetAsync(p.stats_partial, 0, sizeof(unsigned long long) * 8 * (size_t)bt.n * p.render_blocks * (TBLK / 64), s);
   (void)hipLaunchKernel(kernel, dim3(p.render_blocks), b, args, lds, s);
   if (ev1) (void)hipEventRecord(ev1, s);
+  if (count_work) hipLaunchKernelGGL(k_stats_final_batch, dim3(bt.n), dim3(256), 0, s, p, batch, p.render_blocks * (TBLK / 64), p.local_rows * p.width, 1);
 }
 
 void rt_launch_gather_uv(const float* texcoords, const uint32_t* tex_idx, const int32_t* material_ids, const uint32_t* order,

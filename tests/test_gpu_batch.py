@@ -159,11 +159,64 @@ def test_batch_rejects_what_it_does_not_define(rt, plane_mesh):
         with pytest.raises(rt.RtError) as e:
             ctx.render_batch_device(np.stack([U, rt.make_uniforms(64, 72, **PLANE_VIEW)]), o, None, None, None)
         assert e.value.code == -1 and "resolution" in str(e.value)
-        with pytest.raises(rt.RtError) as e:
-            ctx.render_batch_device(np.stack([U, U]), rt.render_opts(mode=rt.MODE_SHADOW, flags=rt.FLAG_COUNT_WORK), None, None, None)
+        with pytest.raises(rt.RtError) as e:                              # counters only of a batch that was asked to count
+            ctx.batch_stats(2)
         assert e.value.code == -1
+        ctx.render_batch_device(np.stack([U, U]), rt.render_opts(mode=rt.MODE_SHADOW, flags=rt.FLAG_COUNT_WORK), None, None, None)
+        with pytest.raises(rt.RtError) as e:
+            ctx.batch_stats(3)                                           # that batch had 2 frames
+        assert e.value.code == -1
+        assert len(ctx.batch_stats(2)) == 2
         with pytest.raises(rt.RtError) as e:
             ctx.render_batch_device(np.stack([U, U]), rt.render_opts_for_mode(rt.MODE_FRAG_WEB), None, None, None)
         assert e.value.code == -1
+    finally:
+        ctx.close()
+
+
+COUNT_KEYS = ("rays_primary", "rays_shadow", "rays_bounce", "box_tests", "tri_tests", "hit_updates", "pixels", "stack_drops", "pixels_traced")
+
+
+def test_batch_counters_equal_the_oracle_per_frame(rt, oracle):
+    """RT_FLAG_COUNT_WORK in a batch (rt_batch_stats): every frame of a 20-frame batch carries its own counters, equal to
+    the oracle's for that frame's view (and so to rt_render_device's), whatever chunks of which frames a wave happened to
+    work on; duplicate views inside a batch (one shared cull / compaction result) count and render like any other frame."""
+    import torch
+    from raytracer_amd import scenes
+    mesh = rt.normalize_mesh(scenes.s70k())
+    ctx = rt.Context(0)
+    try:
+        ctx.set_mesh(mesh)
+        ctx.build_lbvh()
+        f_ = ctx.flatten_for_ssbo()
+        w, h = 243, 135
+        views = [rt.make_uniforms(w, h, cam_pos=(0.0, 0.0, 1.3), rot_deg=(0.0, 1.0 * k, 0.0)) for k in range(18)]   # the bench's camera path
+        Us = views[:7] + [views[3]] + views[7:] + [views[0]]            # 20 frames, two of them duplicates of earlier ones
+        assert len(Us) == 20
+        for mode, extra in ((rt.MODE_SHADOW, {}), (rt.MODE_PT, dict(gi_samples=2, gi_bounces=2))):
+            counted = rt.render_opts(mode=mode, flags=rt.FLAG_COUNT_WORK, **extra)
+            plain = rt.render_opts(mode=mode, **extra)
+            ref = _single(ctx, torch, Us, plain)
+            for rep in range(2):                                         # without and with hints
+                _same(_batch(ctx, torch, Us, counted), ref, f"counted batch, mode {mode}")
+                st = ctx.batch_stats(20)
+                for f in (0, 3, 7, 12, 19) if mode == rt.MODE_PT else range(20):
+                    _, ost = oracle.render(f_["bvhData"], f_["triPos"], f_["triNor"], Us[f], mode=mode, n_threads=8, want=(), **extra)
+                    for k in COUNT_KEYS[:-1]:
+                        assert st[f][k] == ost[k], (mode, rep, f, k, st[f][k], ost[k])
+                    one = ctx.render_device(Us[f], counted)
+                    assert st[f]["pixels_traced"] == one["pixels_traced"]
+                assert st[7] == st[3] and st[19] == st[0]
+            _same(_batch(ctx, torch, Us, plain), ref, "duplicate views, uncounted")
+        # a stripe share counts its own rows only
+        so = rt.render_opts(mode=rt.MODE_SHADOW, flags=rt.FLAG_COUNT_WORK, stripe_rows=16, stripe_rank=1, stripe_world=3)
+        rows = rt.packed_rows(h, 16, 1, 3)
+        _batch(ctx, torch, Us[:5], so, rows=rows)
+        st = ctx.batch_stats(5)
+        for f in range(5):
+            one = ctx.render_device(Us[f], so)
+            for k in COUNT_KEYS:
+                assert st[f][k] == one[k], (f, k)
+            assert st[f]["pixels"] == rows * w
     finally:
         ctx.close()

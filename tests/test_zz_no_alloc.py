@@ -118,3 +118,33 @@ def test_noalloc_textured_and_limits(rt, oracle):
               "1/5 stripe share of 7680x4320")
     finally:
         ctx.close()
+
+
+def test_noalloc_really_allocates_nothing(rt, plane_mesh):
+    """The property the entry point exists for: no hipMalloc / hipFree on its path.  Every device allocation of the library
+    goes through one wrapper that counts its calls (rt_debug_device_allocations); the count must stand still across
+    rt_render_device_noalloc calls at a resolution, in modes and with kernel variants this context has never run - where
+    rt_render_device has to grow its scratch (and does move the count)."""
+    import torch
+    ctx = rt.Context(0)
+    try:
+        ctx.set_mesh(plane_mesh)
+        ctx.build_lbvh()
+        dev = torch.device("cuda:0")
+        out = torch.zeros((1080, 1920), dtype=torch.int32, device=dev)
+        ctx.render_device_noalloc(rt.make_uniforms(64, 64, **PLANE_VIEW), rt.render_opts(mode=rt.MODE_PRIMARY), out.data_ptr(), 0, 0)
+        ctx.synchronize()
+        before = rt.device_allocations()
+        for (w, h), opts in (((1920, 1080), rt.render_opts(mode=rt.MODE_SHADOW)),                                  # larger, another mode
+                             ((320, 200), rt.render_opts(mode=rt.MODE_PT, gi_samples=2)),                           # PT, one lane per pixel
+                             ((640, 360), rt.render_opts(mode=rt.MODE_SHADOW, layout=rt.LAYOUT_AOS32)),            # another kernel variant
+                             ((1920, 1080), rt.render_opts(mode=rt.MODE_SHADOW, stripe_rows=16, stripe_rank=1, stripe_world=2)),
+                             ((800, 600), rt.render_opts_for_mode(rt.MODE_FRAG_ROOT))):
+            ctx.render_device_noalloc(rt.make_uniforms(w, h, **PLANE_VIEW), opts, out.data_ptr(), 0, 0)
+            ctx.synchronize()
+            assert rt.device_allocations() == before, f"rt_render_device_noalloc allocated at {w}x{h}, mode {opts.mode}"
+        ctx.render_device(rt.make_uniforms(1920, 1080, **PLANE_VIEW), rt.render_opts(mode=rt.MODE_SHADOW), out.data_ptr(), 0, 0, want_stats=False)
+        ctx.synchronize()
+        assert rt.device_allocations() > before          # the counter does see rt_render_device growing its scratch
+    finally:
+        ctx.close()
