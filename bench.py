@@ -1,20 +1,25 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of BASELINE.json: Mrays/s, primary + shadow rays, dragon-class
 mesh at 3840x2160 (cfg 3), plus LBVH build ms.  `web/dragon.obj` is a Git-LFS pointer in the
-reference, so the workload is the closed-form stand-in S1M (1 310 720 triangles).
+reference, so the workload is the closed-form stand-in S1M (1 310 720 triangles), textured with the
+reference's own base-colour images (models/Material_85_baseColor.jpg / Material_86_baseColor.png, tests/golden fixtures).
 
   python bench.py --gpus N --steps K --warmup W
   N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one frame(): the traversal kernel over the whole 4K image (inputs resident in HBM),
-for N > 1 sharded as 16-row image-space stripes + RCCL all-gather of the packed stripes +
-de-interleave, all inside the timed region.  The BVH is built once on rank 0 and replicated
-with RCCL broadcasts before the timed region.  Total work is fixed as N grows => "strong".
+A step = one frame(): the traversal kernel over the whole 4K image (inputs resident in HBM).  The K timed frames are K
+DIFFERENT views - the model turns by one degree per frame, as a user dragging the reference's rotY slider - queued as
+pipelines of up to 32 frames (rt_render_batch_device).  For N > 1 every frame is sharded as 16-row image-space stripes +
+RCCL gather of the packed stripes + de-interleave, all inside the timed region; the BVH is built once on rank 0 and
+replicated with RCCL before the timed region.  Total work is fixed as N grows => "strong".
 
-One JSON line on rank 0; `roofline` is the traversal kernel against the HBM roof using the
-ALGORITHMIC bytes of SURVEY §8d (32 V + 48 K + 48 H + 4 P from the kernel's own work counters,
-which tests/test_gpu_render.py proves equal to the oracle's); `cpu_baseline` is the scalar
-oracle timed on the host cores on a bounded sample of the same frame (reported, not a target).
+One JSON line on rank 0.  `value` counts the rays that ENTER the traversal kernel ("rays actually cast / kernel
+time"): primary rays that miss the tree's root box are disposed of by the cull pass and are only in `value_all_pixels`.
+Rays and work counters are the kernels' own, read from a counted run of exactly the timed pipelines (rt_batch_stats;
+tests/test_gpu_batch.py proves them equal to the oracle's per frame).  `roofline` prices the traversal kernel against the
+memory level that serves its bytes (PMC: L2 hits / L2 misses = Infinity Cache + HBM / fabric bytes) and names the binding
+one; the SURVEY 8d algorithmic bytes (32 V + 48 K + 48 H + 4 P) are reported beside it.  `cpu_baseline` is the scalar
+oracle timed on the host cores on a bounded sample of the same frames (reported, not a target).
 """
 import argparse
 import json
@@ -83,8 +88,8 @@ def main():
                     help="N > 1 on a ONE-GPU box: every rank uses cuda:0 and the collectives run over gloo, staged through host memory (RCCL "
                          "refuses two ranks on one device).  Exercises the whole N > 1 code path (replication, stripes, batched exchange, "
                          "de-interleave, reductions); its numbers mean nothing and the line says so")
-    ap.add_argument("--no-fif2", action="store_true", help="skip the extra two-frames-in-flight loop at N = 1")
-    ap.add_argument("--no-legs", action="store_true", help="skip the unhinted and moving-camera legs at N = 1")
+    ap.add_argument("--no-fif2", action="store_true", help="(accepted for old scripts; the two-pipelines-in-flight loop is gone)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the per-frame and static-view legs at N = 1")
     ap.add_argument("--no-texture", action="store_true",
                     help="shade with the reference's constant albedo (compute.wgsl:372) instead of the materials + textures of cfg 3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -165,14 +170,18 @@ def main():
             def set_surface(self, m): pass
             def __getattr__(self, k): return getattr(self.c, k)
         bound = rt.bind_obj_surface(_SurfaceDone(ctx), file_mesh, os.path.dirname(os.path.abspath(args.scene[4:])))
-    elif textured:                      # materials + closed-form textures: small host-side descriptions, set on every rank
+    elif textured:                      # materials + the reference's base-colour images: small host-side data, set on every rank
         from raytracer_amd import scenes
         ctx.set_materials(scenes.STANDIN_MATERIALS)
-        ctx.set_texture(0, scenes.procedural_texture(2048, 0))
-        ctx.set_texture(1, scenes.procedural_texture(1024, 1))
+        for slot, img in enumerate(cfg3_textures()):
+            ctx.set_texture(slot, img)
 
-    # camera (B) of SURVEY §8d: pos (0,0,1.3), default sliders
-    U = rt.make_uniforms(W, H, cam_pos=(0.0, 0.0, 1.3))
+    # camera (B) of SURVEY 8d: pos (0,0,1.3), default sliders; frame k of a loop shows the model turned by k degrees (rotY)
+    def view(k):
+        return rt.make_uniforms(W, H, cam_pos=(0.0, 0.0, 1.3), rot_deg=(0.0, 1.0 * k, 0.0))
+    U = view(0)
+    K = args.steps
+    views = [view(k) for k in range(K)]
     shade = rt.render_opts_for_mode(mode)      # sample counts / stack depth the shader file is written with
     if not frag:
         shade.gi_samples = args.spp
@@ -190,37 +199,50 @@ def main():
     frame = rdist.ShardedFrame(rdist.GpuBackend(ctx, device, frames_in_flight=fif), W, H, rank, world, base, exchange=args.exchange)
     bframes = rdist.BatchedFrames(frame.b, W, H, rank, world, batch, base, exchange=args.exchange) if batch > 1 else None
 
-    def run_frames(views, n):
-        """n steps (frames) of the frame loop, views[i % len(views)] each: one frame per pipeline, or `batch` frames per pipeline."""
-        if bframes is None:
+    def run_frames(vs, n, per_frame=False):
+        """n steps (frames) of the frame loop, vs[i % len(vs)] each: one frame per pipeline, or `batch` frames per pipeline."""
+        if bframes is None or per_frame:
             for i in range(n):
-                frame.step(views[i % len(views)], want_stats=False)
+                frame.step(vs[i % len(vs)], want_stats=False)
             return
         i0 = 0
         for size in rdist.batch_sizes(n, batch):             # pipelines of equal size (K = 20, 16 at most per pipeline: 10 + 10)
-            bframes.step(np.stack([views[i % len(views)] for i in range(i0, i0 + size)]))
+            bframes.step(np.stack([vs[i % len(vs)] for i in range(i0, i0 + size)]))
             i0 += size
 
-    # one counted launch (untimed): rays + work counters of this rank's share of the frame
+    # Rays and work counters of the n frames of a loop (this rank's share), from the kernels' OWN counters of exactly the
+    # pipelines the loop runs: the same batches once more with RT_FLAG_COUNT_WORK (rt_batch_stats), untimed.
     copts = rt.render_opts(mode=mode, layout=layout, flags=rt.FLAG_COUNT_WORK | tflag, **shade,
                            stripe_rows=frame.opts.stripe_rows, stripe_rank=rank, stripe_world=world)
-    def counted(Uc):
-        """Rays and algorithmic bytes of one frame (this rank's share), from the kernels' own work counters.
-        -> (rays as the reference's loop casts them, rays that enter the tree, bytes of the whole frame, k_render's own bytes).
-        Pixels whose primary ray misses the root box never reach k_render (k_cull disposes of them, most of them through a
-        screen rectangle): k_stats_final counts each as one ray + one box test + one pixel, and those 36 B are NOT k_render's."""
-        c = ctx.render_device(Uc, copts, d_rgba8=frame.packed.data_ptr())
-        culled = c["pixels"] - c["pixels_traced"]
-        rays = c["rays_primary"] + c["rays_shadow"] + c["rays_bounce"]
-        frame_bytes = 32 * c["box_tests"] + 48 * c["tri_tests"] + 48 * c["hit_updates"] + 4 * c["pixels"]
-        return rays, rays - culled, frame_bytes, frame_bytes - 36 * culled
+    scratch_img = torch.zeros((batch, frame.rpr if world > 1 else H, W), dtype=torch.int32, device=device)
 
-    my_rays, my_rays_traced, my_frame_bytes, my_bytes = counted(U)
+    def counted(vs, n, per_frame=False):
+        """-> per frame (rays as the reference's loop casts them, rays that enter the tree, SURVEY 8d bytes of the whole frame,
+        k_render's own bytes), and the counting kernels' average launch time.  Pixels whose primary ray misses the root box never
+        reach k_render (k_cull disposes of them): each is one ray + one box test + one pixel, and those 36 B are NOT k_render's."""
+        per = []
+        ctx.profile_begin()
+        if bframes is None or per_frame:
+            sts = [ctx.render_device(vs[i % len(vs)], copts, d_rgba8=scratch_img[0].data_ptr()) for i in range(n)]
+        else:
+            sts, i0 = [], 0
+            for size in rdist.batch_sizes(n, batch):
+                ctx.render_batch_device(np.stack([vs[i % len(vs)] for i in range(i0, i0 + size)]), copts,
+                                        [scratch_img[f].data_ptr() for f in range(size)])
+                sts += ctx.batch_stats(size)
+                i0 += size
+        _, cms, _ = ctx.profile_end()
+        for c in sts:
+            culled = c["pixels"] - c["pixels_traced"]
+            rays = c["rays_primary"] + c["rays_shadow"] + c["rays_bounce"]
+            fb = 32 * c["box_tests"] + 48 * c["tri_tests"] + 48 * c["hit_updates"] + 4 * c["pixels"]
+            per.append((rays, rays - culled, fb, fb - 36 * culled))
+        return per, cms
 
-    if bframes is not None:             # set-up, like the counted launch above: the first full batch sizes the pipeline's scratch
-        bframes.step(np.stack([U] * batch))
+    if bframes is not None:             # set-up (untimed): the first full batch sizes the pipeline's scratch
+        bframes.step(np.stack([view(k) for k in range(batch)]))
         bframes.finish()
-    run_frames([U], args.warmup)
+    run_frames(views, args.warmup)
 
     def fence():
         frame.finish()
@@ -231,90 +253,62 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    fence()
-    t0 = time.perf_counter()
-    # frames are queued asynchronously, as a frame loop would; hipEvents recorded on the context's own stream
-    # around every frame's kernels (rt_profile_begin/end) give the per-kernel durations of exactly these K steps
-    ctx.profile_begin()
-    run_frames([U], args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
-    kernel_ms, trav_ms, n_launch = ctx.profile_end()   # frame pipeline (cull, compact, traversal, stats) / k_render alone, per launch
-    frames_per_launch = args.steps / max(n_launch, 1)  # 1, or the mean batch size (a k_render launch then walks that many frames' lists)
+    def timed(vs, n, per_frame=False):
+        """The loop under the clock: barrier + synchronize on both sides; hipEvents recorded on the context's own stream around
+        every pipeline's kernels (rt_profile_begin/end) give the kernel durations of exactly these n steps."""
+        fence()
+        t0 = time.perf_counter()
+        ctx.profile_begin()
+        run_frames(vs, n, per_frame)
+        fence()
+        e = time.perf_counter() - t0
+        pipe_ms, trav_ms, launches = ctx.profile_end()     # per launch: frame pipeline (cull, scan, compact, traversal) / k_render alone
+        return e, pipe_ms, trav_ms, launches
+
+    elapsed, kernel_ms, trav_ms, n_launch = timed(views, K)
+    frames_per_launch = K / max(n_launch, 1)               # 1, or the mean batch size (a k_render launch then walks that many frames' lists)
+    per, counted_ms = counted(views, K)
+    my_rays, my_rays_traced = sum(p[0] for p in per), sum(p[1] for p in per)
+    my_frame_bytes, my_bytes = sum(p[2] for p in per), sum(p[3] for p in per)
 
     # N > 1: the frame rank 0 assembled from all ranks' stripes (the last timed one) against rank 0's own render of the whole
     # frame — outside the timed region; says on the driver's 8-GPU run that the exchange delivered the right pixels
     frame_check = None
     if world > 1 and rank == 0:
         try:
-            assembled = bframes.images[0] if bframes is not None else frame.image
+            if bframes is not None:     # (the counted run wrote into its own buffer: bframes.images still holds the timed loop's last pipeline)
+                first_of_last = K - rdist.batch_sizes(K, batch)[-1]
+                assembled, shown = bframes.images[0], views[first_of_last]
+            else:
+                assembled, shown = frame.image, views[K - 1]
             whole = torch.zeros((H, W), dtype=torch.int32, device=device)
-            ctx.render_device(U, base, d_rgba8=whole.data_ptr(), want_stats=False)
+            ctx.render_device(shown, base, d_rgba8=whole.data_ptr(), want_stats=False)
             ctx.synchronize()
             frame_check = "identical" if torch.equal(whole, assembled) else f"{int((whole != assembled).sum())} pixels differ"
         except Exception as e:          # (a check outside the timed region must not cost the line)
             frame_check = f"check failed: {type(e).__name__}: {e}"
 
-    # the same K frames again with two frames in flight (only where the main loop ran with one): whole-job throughput when
-    # the tail of one frame may overlap the head of the next; reported beside `value`, never as `value` at N = 1
-    fif2 = None
-    if fif == 1 and world == 1 and not args.no_fif2 and (batch == 1 or len(rdist.batch_sizes(args.steps, batch)) > 1):   # (one pipeline: nothing to overlap)
-        b2 = rdist.GpuBackend(ctx, device, frames_in_flight=2)
-        if batch > 1:                   # two BATCHES in flight: cull / compaction and the head of batch i+1 beside the tail of batch i
-            frame2 = rdist.BatchedFrames(b2, W, H, rank, world, batch, base)
-            go = lambda n: [frame2.step(np.stack([U] * size)) for size in rdist.batch_sizes(n, batch)]
-            go(2 * batch)               # both frame slots size their scratch
-        else:
-            frame2 = rdist.ShardedFrame(b2, W, H, rank, world, base)
-            go = lambda n: [frame2.step(U, want_stats=False) for _ in range(n)]
-        go(args.warmup)
-        frame2.finish()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        go(args.steps)
-        frame2.finish()
-        torch.cuda.synchronize()
-        e2 = time.perf_counter() - t1
-        fif2 = {"value": round(my_rays * args.steps / e2 / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(e2 / args.steps * 1e3, 4),
-                "what": "the same K steps with two pipelines in flight (overlapped launches stretch each other, so their durations no "
-                        "longer measure the kernel: reported beside `value`, never as `value`)"}
-        ctx.set_frames_in_flight(1)
-
-    # Two more legs at N = 1, same frame loop, reported beside `value` (never as `value`): the same static view WITHOUT the
-    # frame-coherent scheduling hints, and a view that changes every frame (the model turning 1 degree per frame, as a user
-    # dragging the reference's rotY slider), where last frame's per-pixel hints are a few pixels off.
+    # Legs at N = 1, reported beside `value` (never as `value`): the same camera path with ONE frame per pipeline (the
+    # latency-bound loop of an interactive viewer, what the reference's frame() is), and a STATIC view in batches (K copies of
+    # view 0: what round 2 reported as `value` - the copies share cache lines and run with converged scheduling hints).
     legs = {}
     if world == 1 and not args.no_legs:
-        def leg(uniforms_list, rays_list, bytes_list, per_frame=False):
-            go = (lambda n: [frame.step(uniforms_list[i % len(uniforms_list)], want_stats=False) for i in range(n)]) if per_frame \
-                else (lambda n: run_frames(uniforms_list, n))
-            go(max(args.warmup, batch))
-            fence()
-            t1 = time.perf_counter()
-            ctx.profile_begin()
-            go(args.steps)
-            fence()
-            e = time.perf_counter() - t1
-            _, tr_ms, launches = ctx.profile_end()
-            n = args.steps
-            rays = sum(rays_list[i % len(rays_list)] for i in range(n))
-            byts = sum(bytes_list[i % len(bytes_list)] for i in range(n))
-            ach = byts / (tr_ms * launches * 1e-3) / 1e9 if tr_ms > 0 else 0.0      # all launches' bytes / all launches' time
-            return {"value": round(rays / e / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(e / n * 1e3, 4),
-                    "kernel_ms": round(tr_ms, 4), "frames_per_launch": round(n / max(launches, 1), 3), "roofline_frac": round(ach / HBM_PEAK_GBS, 5)}
+        def leg(vs, per_frame):
+            run_frames(vs, max(args.warmup, batch if not per_frame else 3), per_frame)
+            e, _, tr_ms, launches = timed(vs, K, per_frame)
+            pr, _ = counted(vs, K, per_frame)
+            traced, byts = sum(p[1] for p in pr), sum(p[3] for p in pr)
+            return {"value": round(traced / e / 1e6, 2), "unit": "Mrays/s", "value_all_pixels": round(sum(p[0] for p in pr) / e / 1e6, 2),
+                    "ms_per_step": round(e / K * 1e3, 4), "kernel_ms": round(tr_ms, 4), "frames_per_launch": round(K / max(launches, 1), 3),
+                    "algorithmic_gbs": round(byts / (tr_ms * launches * 1e-3) / 1e9, 1) if tr_ms > 0 else None}
         if batch > 1:
-            legs["per_frame"] = leg([U], [my_rays], [my_bytes], per_frame=True)
-            legs["per_frame"]["what"] = "same static view, ONE frame per pipeline (rt_render_device, one frame in flight): the latency-bound loop of an interactive viewer"
-        ctx.set_coherent_scheduling(False)
-        legs["unhinted"] = leg([U], [my_rays], [my_bytes])
-        legs["unhinted"]["what"] = "same static view, frame-coherent scheduling hints off (a first frame / camera cut runs at this speed)"
-        ctx.set_coherent_scheduling(True)
-        views = [rt.make_uniforms(W, H, cam_pos=(0.0, 0.0, 1.3), rot_deg=(0.0, 1.0 * k, 0.0)) for k in range(max(args.steps, 8))]
-        cnt = [counted(v) for v in views]
-        legs["moving_camera"] = leg(views, [c[0] for c in cnt], [c[3] for c in cnt])
-        legs["moving_camera"]["what"] = ("rotY + 1 degree per frame; a batch whose views differ is not ordered by hints (they would be a batch old)"
-                                         if batch > 1 else "rotY + 1 degree per frame, hints on (tile-level promotion under motion)")
-        run_frames([U], 3 * batch)      # leave the context as the main loop had it: hints of the static view
+            legs["per_frame"] = leg(views, True)
+            legs["per_frame"]["what"] = ("the same camera path, ONE frame per pipeline (rt_render_device, one frame in flight): the latency-bound loop of "
+                                         "an interactive viewer; scheduling hints with tile-level promotion under motion")
+            legs["static_view"] = leg([U], False)
+            legs["static_view"]["what"] = (f"{K} copies of view 0 in the same pipelines (round 2's headline loop): identical frames share cache "
+                                           "lines and are ordered by converged scheduling hints - not a workload, kept for comparison")
+        run_frames(views, batch)        # leave the context as the main loop had it
         fence()
 
     tot = torch.tensor([float(my_rays), float(my_bytes), elapsed, kernel_ms, float(my_rays_traced)], dtype=torch.float64,
@@ -329,11 +323,9 @@ def main():
     total_rays, total_bytes, total_traced = float(tot[0]), float(tot[1]), float(tot[4])
 
     if rank == 0:
-        pmc = pmc_traffic(args, world, textured, batch, frames_per_launch)
-        ms_per_step = elapsed / args.steps * 1e3
-        value = total_rays * args.steps / elapsed / 1e6
-        # roofline of the dominant kernel (traversal): this rank's algorithmic bytes / its average launch duration
-        achieved = my_bytes * frames_per_launch / (trav_ms * 1e-3) / 1e9 if trav_ms > 0 else 0.0
+        ms_per_step = elapsed / K * 1e3
+        value = total_traced / elapsed / 1e6
+        launch_bytes = my_bytes / max(n_launch, 1)         # this rank's algorithmic bytes per k_render launch
         what = {"primary": "primary rays only", "shadow": "primary + 4 soft shadow rays",
                 "pt": f"full computeLighting_optimized: GI {args.spp} spp x 3 bounces + 4 soft shadow rays per vertex",
                 "frag-web": "web/shader.wgsl computeLighting_optimized: GI 32 x 3 bounces, 8-tap Poisson-disk light per vertex",
@@ -341,42 +333,35 @@ def main():
         scene_txt = {"s1m": "cfg3: S1M closed-form icosphere stand-in for dragon.obj",
                      "s70k": "cfg1-2: S70k closed-form icosphere stand-in for bunny.obj"}.get(
                          args.scene, f"mesh file {os.path.basename(args.scene[4:])}" if from_file else f"cfg5: {args.scene[7:]} copies of S1M on a lattice, flattened")
+        tex_txt = ((f"textured shading: the file's {len(file_mesh.materials)} materials, map_Kd images bound: {[n for n, _ in bound] or 'none found (Kd only)'}, nearest texel"
+                    if from_file else "textured shading: 3 materials, map_Kd = the reference's models/Material_85_baseColor.jpg and Material_86_baseColor.png "
+                                      "(tests/golden fixtures: box-filtered to 512^2, replicated back to their 2048^2 texels), nearest texel") if textured
+                   else "constant albedo (compute.wgsl:372)")
         out = {
             "metric": "Mrays/s primary+shadow, dragon.obj 4K" if (args.mode == "shadow" and args.scene == "s1m" and (W, H) == (3840, 2160))
                       else f"Mrays/s {args.mode} {args.scene} {W}x{H}",
-            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{scene_txt} ({build['n_tri']} triangles), {W}x{H}, {what}, camera B (0,0,1.3), "
-                                   f"layout {args.layout}, node records {'v2' if encoding == rt.NODES_V2 else 'v1'}, "
-                                   + ((f"textured shading: the file's {len(file_mesh.materials)} materials, map_Kd images bound: {[n for n, _ in bound] or 'none found (Kd only)'}, nearest texel"
-                                       if from_file else "textured shading: 3 materials, map_Kd 2048^2 + 1024^2 closed-form RGB8, nearest texel") if textured
-                                      else "constant albedo (compute.wgsl:372)"),
-                       "mode": args.mode, "rays_per_frame": int(total_rays), "rays_traced_per_frame": int(total_traced), "frames_in_flight": fif, "frames_per_pipeline": batch, "stripes": "16-row round-robin" if world > 1 else "none",
+            "config": {"workload": f"{scene_txt} ({build['n_tri']} triangles), {W}x{H}, {what}, camera B (0,0,1.3), a camera path of {K} DIFFERENT views "
+                                   f"(the model turns 1 degree per frame), {batch} frame(s) per pipeline at most, layout {args.layout}, "
+                                   f"node records {'v2' if encoding == rt.NODES_V2 else 'v1'}, {tex_txt}",
+                       "mode": args.mode, "rays_traced_per_frame": int(total_traced / K), "rays_all_pixels_per_frame": int(total_rays / K),
+                       "frames_in_flight": fif, "frames_per_pipeline": batch, "stripes": "16-row round-robin" if world > 1 else "none",
                        "exchange": ("gather to rank 0" if args.exchange == "root" else "all_gather") if world > 1 else "none"},
+            # `value` = rays that ENTER the traversal kernel (k_render's input); value_all_pixels also counts one primary ray for every
+            # pixel the cull pass disposes of, as the reference's per-pixel loop casts it (compute.wgsl:268-275)
+            "value_all_pixels": round(total_rays / elapsed / 1e6, 2),
             "lbvh_build_ms": {k: round(float(v), 4) for k, v in build.items() if k.startswith("ms_")},
             "lbvh_build_wall_ms": round(build_wall_ms, 4),     # host clock around rt_build_lbvh (launches + events + the read-back)
             "lbvh_build_roofline_frac": round(build["algorithmic_bytes"] / (build["ms_total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
             "bvh_broadcast_ms": round(bcast_ms, 3),
             "frame_kernels_ms": round(kernel_ms, 4), "frame_kernels_ms_max_rank": round(kernel_max, 4),
-            # rays that actually enter the tree (k_render's input): `value` also counts one primary ray for every pixel the
-            # cull pass disposes of, as the reference's per-pixel loop casts it (compute.wgsl:268-275)
-            "value_traced": round(total_traced * args.steps / elapsed / 1e6, 2),
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc.get("k_render_hbm_bytes_per_launch"),
-                         "traffic_source": pmc.get("source"),
-                         "kernel": "k_render", "kernel_ms": round(trav_ms, 4), "algorithmic_bytes_per_launch": int(my_bytes * frames_per_launch),
-                         "frames_per_launch": round(frames_per_launch, 3),
-                         "bytes_outside_kernel": int(my_frame_bytes - my_bytes),
-                         # what actually binds the kernel: its working set is cache-resident, fabric traffic is a
-                         # small share of the HBM roof, and the VALU lanes are half idle behind divergent 64-byte gathers
-                         "fabric_frac": (round(pmc["k_render_hbm_bytes_per_launch"] / (trav_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-                                         if pmc.get("k_render_hbm_bytes_per_launch") and trav_ms > 0 else None),
-                         "valu_lane_util": pmc.get("k_render_valu_lane_util"),
-                         "note": "achieved = SURVEY 8d's algorithmic bytes (32 B per box test, 48 per triangle test, 48 per hit update, 4 per pixel) / "
-                                 "kernel time; the records come out of L2 / Infinity Cache (fabric traffic = `traffic`, ~17x less), so frac can "
-                                 "pass 1: the kernel is bound by dependent 64-byte gathers, not by HBM"},
+            "roofline": roofline(args, world, textured, batch, frames_per_launch, trav_ms, launch_bytes, counted_ms,
+                                 int(my_frame_bytes - my_bytes) // max(n_launch, 1)),
         }
+        if "per_frame" in legs:
+            out["value_per_frame"] = legs["per_frame"]["value"]      # one frame per pipeline: comparable with round 1's loop
         if frame_check is not None:
             out["assembled_frame_vs_single_gpu_render"] = frame_check
         if world > 1 and bframes is not None and bframes.windowed and bframes.window[0] is not None:
@@ -388,10 +373,8 @@ def main():
             out["rehearsal"] = f"{world} ranks sharing cuda:0, collectives over gloo: exercises the N > 1 code path, NOT a measurement"
         if legs:
             out["legs"] = legs
-        if fif2 is not None:
-            out["two_pipelines_in_flight" if batch > 1 else "two_frames_in_flight"] = fif2
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(args, mesh, U, mode, textured, shade)
+            out["cpu_baseline"] = cpu_baseline(args, mesh, views, mode, textured, shade)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
@@ -399,11 +382,72 @@ def main():
     ctx.close()
 
 
-def pmc_traffic(args, world, textured, batch, frames_per_launch):
-    """HBM bytes per k_render launch from the PMC passes (scripts/pmc_passes.sh -> scripts/pmc_summary.py,
-    2 x FETCH_SIZE + WRITE_SIZE per MI355X_MICROARCH.md), committed as profiles/traffic.json.  The counters
-    need rocprofv3 runs of their own, so the figure is read back from the last committed collection and is
-    only reported when that collection was made on this exact workload; otherwise null."""
+def cfg3_textures():
+    """The reference's two base-colour images of models/plane_material.mtl (the only map_Kd images its tree holds next to a mesh
+    that is present; SURVEY 8d row 3 names Material_85_baseColor.jpg), from the fixtures tests/golden/make_textures.py wrote:
+    box-filtered 2048^2 -> 512^2 there, replicated here 4 x 4 back to 2048^2 texels so that the texture footprint in memory is
+    the original's.  -> [texture slot 0, texture slot 1] as uint8 [2048, 2048, 3]."""
+    import gzip
+    out = []
+    for name in ("Material_85_baseColor_512.ppm.gz", "Material_86_baseColor_512.ppm.gz"):
+        raw = gzip.open(os.path.join(ROOT, "tests", "golden", name), "rb").read()
+        assert raw.startswith(b"P6\n512 512\n255\n")
+        img = np.frombuffer(raw, np.uint8, 512 * 512 * 3, len(b"P6\n512 512\n255\n")).reshape(512, 512, 3)
+        out.append(np.ascontiguousarray(np.repeat(np.repeat(img, 4, axis=0), 4, axis=1)))
+    return out
+
+
+# peaks of the memory levels (MI355X_MICROARCH.md): L2 ~34.5 TB/s aggregate; random rows of an Infinity-Cache-resident table of
+# k_render's size (wide 84 MB + tri_pre 63 MB: between the guide's 38 MB and 151 MB rows, 8.6 and 7.4-7.9 TB/s) - the higher
+# figure is used, so the fraction errs low; HBM 8 TB/s
+L2_PEAK_GBS, IC_PEAK_GBS = 34500.0, 8600.0
+
+
+def roofline(args, world, textured, batch, frames_per_launch, trav_ms, launch_bytes, counted_ms, bytes_outside):
+    """The traversal kernel against the memory level that serves its bytes.  Time: the kernel's average launch duration over
+    exactly the timed steps (hipEvents on its own stream).  Bytes per level: PMC counters of the same command, collected by
+    rocprofv3 runs of their own (scripts/pmc_passes.sh -> scripts/pmc_summary.py -> profiles/traffic.json, committed), per frame
+    of the collection's launches, scaled to this run's frames per launch:
+        L2 hit bytes   = TCC_HIT_sum  x 128 B  (L2 line; calibrated by tools/pmc_calib on a known streaming read)  vs 34.5 TB/s
+        L2 miss bytes  = TCC_MISS_sum x 128 B  (served by Infinity Cache or HBM)                                   vs  8.6 TB/s
+        fabric bytes   = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (the guide's gfx950 correction; Infinity-Cache hits are
+                         counted in it, so an upper bound on HBM bytes)                                            vs  8.0 TB/s
+    `bound` = the level with the largest fraction, `achieved` / `peak` / `frac` are that level's.  The SURVEY 8d algorithmic
+    bytes (32 B per box test, 48 per triangle test, 48 per hit update, 4 per pixel; the kernel's own counters) are `algorithmic_*`:
+    they are served out of L1 / L2 several times over, which is why they are NOT a byte roof of any level.
+    Without a collection for this exact workload the levels are unknown: the algorithmic bytes are then priced against the L2
+    peak (every one of them crosses L1 <- L2 at most once) and `traffic` is null."""
+    t = trav_ms * 1e-3
+    r = {"kernel": "k_render", "kernel_ms": round(trav_ms, 4), "frames_per_launch": round(frames_per_launch, 3),
+         "algorithmic_bytes_per_launch": int(launch_bytes), "algorithmic_gbs": round(launch_bytes / t / 1e9, 1) if t > 0 else None,
+         "bytes_outside_kernel_per_launch": int(bytes_outside), "kernel_ms_counting": round(counted_ms, 4)}
+    pmc = pmc_levels(args, world, textured, batch)
+    if not pmc or t <= 0:
+        ach = launch_bytes / t / 1e9 if t > 0 else 0.0
+        r.update({"bound": "l2", "achieved": round(ach, 1), "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": round(ach / L2_PEAK_GBS, 5), "traffic": None,
+                  "note": "no PMC collection for this workload (profiles/traffic.json): algorithmic bytes against the L2 peak"})
+        return r
+    k = frames_per_launch                                  # counters are stored per FRAME of the collection's launches
+    levels = {}
+    for name, per_frame, peak in (("l2_hit", pmc["l2_hit_bytes_per_frame"], L2_PEAK_GBS), ("l2_miss", pmc["l2_miss_bytes_per_frame"], IC_PEAK_GBS),
+                                  ("fabric", pmc["fabric_bytes_per_frame"], HBM_PEAK_GBS)):
+        gbs = per_frame * k / t / 1e9
+        levels[name] = {"bytes_per_launch": int(per_frame * k), "achieved": round(gbs, 1), "peak": peak, "frac": round(gbs / peak, 5)}
+    bound = max(levels, key=lambda n: levels[n]["frac"])
+    r.update({"bound": {"l2_hit": "l2", "l2_miss": "infinity_cache", "fabric": "hbm"}[bound], "achieved": levels[bound]["achieved"],
+              "peak": levels[bound]["peak"], "unit": "GB/s", "frac": levels[bound]["frac"],
+              "traffic": levels["fabric"]["bytes_per_launch"], "levels": levels,
+              "l2_hit_rate": pmc.get("l2_hit_rate"), "valu_lane_util": pmc.get("valu_lane_util"), "ta_busy": pmc.get("ta_busy"),
+              "traffic_source": pmc.get("source"),
+              "note": "frac = the busiest memory level's bytes / kernel time / that level's peak (levels: L2 hits vs 34.5 TB/s, L2 misses vs the "
+                      "8.6 TB/s random-row rate of the Infinity Cache, fabric bytes vs 8 TB/s HBM).  All three are far from their peaks: the kernel "
+                      "is bound by the rate at which a CU's vector-memory path takes divergent 64-byte record fetches (tools/ubench_fat: ~113 ns per "
+                      "128-B line + ~67 ns per 64-B sector per 64 lanes per CU), `ta_busy` is the address unit's busy share"})
+    return r
+
+
+def pmc_levels(args, world, textured, batch):
+    """Per-frame PMC byte counts of k_render from the committed collection, only when it was made on this exact workload."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         t = json.load(open(path))
@@ -412,20 +456,17 @@ def pmc_traffic(args, world, textured, batch, frames_per_launch):
     w = t.get("workload", {})
     same = (world == 1 and w.get("scene") == args.scene and w.get("width") == args.width and w.get("height") == args.height
             and w.get("mode") == args.mode and w.get("layout") == args.layout and (args.mode != "pt" or w.get("spp") == args.spp)
-            and bool(w.get("textured", False)) == textured)
-    if not same:
+            and bool(w.get("textured", False)) == textured and int(w.get("frames_per_pipeline", 1)) == batch
+            and w.get("camera_path") == "rotY 1 degree per frame")
+    if not same or "k_render" not in t:
         return {}
-    if int(w.get("frames_per_pipeline", 1)) != batch:
-        return {}
-    # counters are per launch of the collection run; this run's launches may hold another number of frames (K = 20 -> 10 + 10)
-    per_frame = t.get("k_render_hbm_bytes_per_launch", 0) / max(float(t.get("frames_per_launch", 1.0)), 1e-9)
-    return {"k_render_hbm_bytes_per_launch": int(per_frame * frames_per_launch), "k_render_valu_lane_util": t.get("k_render_valu_lane_util"),
-            "source": "profiles/traffic.json: " + str(t.get("source", ""))}
+    return dict(t["k_render"], source="profiles/traffic.json: " + str(t.get("source", "")))
 
 
-def cpu_baseline(args, mesh, U, mode, textured, shade):
-    """The scalar oracle ("port") on the host cores, on a bounded sample of the same frame:
-    every k-th row of the 4K image, k chosen so that the sample takes ~10-30 s of CPU time."""
+def cpu_baseline(args, mesh, views, mode, textured, shade):
+    """The scalar oracle ("port") on the host cores, on a bounded sample of the same frames: every k-th row of the image,
+    k chosen so that the sample takes ~10-30 s of CPU time, the repeats walking through the camera path's views."""
+    U = views[0]
     from oracle import binding as oracle     # checker / baseline only — never on the product path
     cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count() or 1))
     enc = 2 if 2 * mesh.n_tri - 1 > (1 << 24) or args.encoding == "v2" else 1
@@ -434,7 +475,7 @@ def cpu_baseline(args, mesh, U, mode, textured, shade):
     if textured:
         from raytracer_amd import scenes
         surf = oracle.Surface(oracle.gather_tri_uv(mesh.texcoords, mesh.tex_idx, mesh.material_ids, b["order"]), scenes.STANDIN_MATERIALS,
-                              [scenes.procedural_texture(2048, 0), scenes.procedural_texture(1024, 1)])
+                              cfg3_textures())
     H = args.height
     # probe: 8 rows spread over the frame
     _, st = oracle.render(b["nodes"], b["tri_pos"], b["tri_nor"], U, mode=mode, **shade, rows=(0, H, max(1, H // 8)),
@@ -447,7 +488,7 @@ def cpu_baseline(args, mesh, U, mode, textured, shade):
     secs = 0.0
     reps = 0
     while reps < 2 or (secs * cores < args.cpu_seconds and reps < 64):
-        _, st = oracle.render(b["nodes"], b["tri_pos"], b["tri_nor"], U, mode=mode, **shade, rows=(0, H, step),
+        _, st = oracle.render(b["nodes"], b["tri_pos"], b["tri_nor"], views[reps % len(views)], mode=mode, **shade, rows=(0, H, step),
                               n_threads=cores, want=(), encoding=enc, surface=surf)
         rays += st["rays_primary"] + st["rays_shadow"] + st["rays_bounce"]
         secs += st["seconds"]
@@ -458,8 +499,9 @@ def cpu_baseline(args, mesh, U, mode, textured, shade):
     single = (s1["rays_primary"] + s1["rays_shadow"] + s1["rays_bounce"]) / max(s1["seconds"], 1e-9) / 1e6
     return {"value": round(rays / secs / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
             "single_thread_value": round(single, 3),
-            "sample": f"rows 0..{H} step {step} of the same {args.width}x{H} frame ({len(range(0, H, step))} rows) x {reps} "
-                      f"repeats: {rays} rays in {secs:.2f} s wall on {cores} threads ({secs * cores:.1f} s of CPU work)",
+            "what": "all rays the reference's loop casts (one per pixel + shadow / bounce rays): compare with value_all_pixels",
+            "sample": f"rows 0..{H} step {step} of the first {min(reps, len(views))} views of the same {args.width}x{H} camera path "
+                      f"({len(range(0, H, step))} rows each): {rays} rays in {secs:.2f} s wall on {cores} threads ({secs * cores:.1f} s of CPU work)",
             "lbvh_build_ms": round(b["seconds"] * 1e3, 2), "lbvh_build_cores": 1}
 
 
