@@ -127,6 +127,7 @@ struct rt_ctx {
   // render scratch, one set per frame slot (slot 0 = the context stream; slots 0/1 alternate with two frames in flight)
   static constexpr int MAX_FIF = 4;            // frame slots (rt_set_frames_in_flight)
   DevBuf<uint32_t> r_tile_counter[MAX_FIF], r_list[MAX_FIF];
+  DevBuf<uint32_t> r_hits[MAX_FIF];            // traverse / shade split: the primary hit's triangle per list entry
   DevBuf<RtFrameRec> r_frames[MAX_FIF];        // a batch's per-frame records (rt_internal.h)
   DevBuf<float4> pt_recs[MAX_FIF];             // PT split records (rt_trace.hip), per frame slot
   DevBuf<float> pt_terms[MAX_FIF];
@@ -295,7 +296,7 @@ extern "C" void rt_destroy(rt_ctx* ctx) {
   for (auto& t : ctx->texels) t.release();
   ctx->tex_table.release();
   for (int k = 0; k < rt_ctx::MAX_FIF; ++k) {
-    ctx->r_tile_counter[k].release(); ctx->r_list[k].release(); ctx->r_frames[k].release(); ctx->r_stats[k].release(); ctx->r_bstats[k].release(); ctx->pt_recs[k].release(); ctx->pt_terms[k].release();
+    ctx->r_tile_counter[k].release(); ctx->r_list[k].release(); ctx->r_hits[k].release(); ctx->r_frames[k].release(); ctx->r_stats[k].release(); ctx->r_bstats[k].release(); ctx->pt_recs[k].release(); ctx->pt_terms[k].release();
     if (ctx->fstream[k]) { (void)hipStreamSynchronize(ctx->fstream[k]); (void)hipStreamDestroy(ctx->fstream[k]); }
     if (ctx->f_done[k]) (void)hipEventDestroy(ctx->f_done[k]);
   }
@@ -980,7 +981,14 @@ int render_frame(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* op
   } else {
     JOIN_FRAMES();
   }
-  const size_t tc_words = 2 * (size_t)rt_shard_words() + 32 + 64 + (size_t)rt_n_class() * cull_blocks;
+  // RT_MODE_PRIMARY / SHADOW frames run as two launches (rt_trace.hip KIND_TRAVERSE / KIND_SHADE); the no-alloc entry point keeps
+  // the whole pixel in one launch (its static array has no room for a hit buffer), RTCORE_TWO_PHASE=0 does so everywhere (A/B)
+  // A SINGLE frame keeps the whole pixel in one launch: its launch time is its longest chain of dependent fetches, which more
+  // resident waves only stretch (k_render 0.54 ms against 0.49 + 0.19 ms for the two launches, profiles/r3/ab_two_phase.txt);
+  // RTCORE_TWO_PHASE=1 forces the split (A/B, tests)
+  bool two_phase = false;
+  if (const char* e = std::getenv("RTCORE_TWO_PHASE")) two_phase = !noalloc && (opts->mode == RT_MODE_PRIMARY || opts->mode == RT_MODE_SHADOW) && std::atoi(e) != 0;
+  const size_t tc_words = 3 * (size_t)rt_shard_words() + 32 + 64 + (size_t)rt_n_class() * cull_blocks;
   const size_t st_words = 8 + 32 + (size_t)rt_render_grid(ctx->n_cu) * 8 + (size_t)rt_n_class() * p.n_tiles;
   const size_t list_words = (size_t)p.local_rows * p.width;
   uint32_t* sc_tc; unsigned long long* sc_st; uint32_t* sc_list;
@@ -1002,6 +1010,7 @@ int render_frame(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* op
     HIPCHK(ctx->r_stats[slot].ensure(st_words));
     if (ctx->r_stats[slot].p != st_before) ctx->class_partial_reset[slot] = true;   // the step histogram lives there
     HIPCHK(ctx->r_list[slot].ensure(list_words));
+    if (two_phase) HIPCHK(ctx->r_hits[slot].ensure(list_words));
     sc_tc = ctx->r_tile_counter[slot].p; sc_st = ctx->r_stats[slot].p; sc_list = ctx->r_list[slot].p;
   }
   p.shard_stride = rt_shard_stride();
@@ -1032,6 +1041,7 @@ int render_frame(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* op
   p.pt_heads = sc_tc + rt_shard_words() + 32;
   p.pt_count = p.pt_heads + rt_shard_words();
   p.block_total = p.pt_count + 64;
+  if (two_phase) { p.shade_heads = p.block_total + (size_t)rt_n_class() * cull_blocks; p.hits = ctx->r_hits[slot].p; }
   p.list = sc_list;
   p.stats = sc_st; p.stats_partial = sc_st + 8 + 32;
   p.class_hist = reinterpret_cast<uint32_t*>(sc_st + 8);   // 64 u32
@@ -1155,13 +1165,16 @@ int render_batch(rt_ctx* ctx, uint32_t n_frames, const float* uniforms, const rt
   bt.bt_stride = rt_n_class() * cull_blocks;
   bt.list_stride = (uint32_t)list_words;
   bt.lc_stride = RT_LC_WORDS;
-  const size_t tc_words = (size_t)rt_shard_words() + (size_t)RT_LC_WORDS * n_frames + (size_t)bt.bt_stride * n_frames;
+  bool two_phase = opts->mode == RT_MODE_PRIMARY || opts->mode == RT_MODE_SHADOW;
+  if (const char* e = std::getenv("RTCORE_TWO_PHASE")) two_phase = two_phase && std::atoi(e) != 0;
+  const size_t tc_words = 2 * (size_t)rt_shard_words() + (size_t)RT_LC_WORDS * n_frames + (size_t)bt.bt_stride * n_frames;
   const size_t st_words = 8 + 32 + (size_t)bt.mask_stride * n_frames;
   HIPCHK(ctx->r_tile_counter[slot].ensure(tc_words));
   const unsigned long long* st_before = ctx->r_stats[slot].p;
   HIPCHK(ctx->r_stats[slot].ensure(st_words));
   if (ctx->r_stats[slot].p != st_before) ctx->class_partial_reset[slot] = true;
   HIPCHK(ctx->r_list[slot].ensure(list_words * n_frames));
+  if (two_phase) HIPCHK(ctx->r_hits[slot].ensure(list_words * n_frames));
   const bool count_work = (opts->flags & RT_FLAG_COUNT_WORK) != 0;
   if (count_work) HIPCHK(ctx->r_bstats[slot].ensure((size_t)RT_MAX_BATCH * 9 + (size_t)n_frames * rt_render_grid(ctx->n_cu) * 4 * 8));
   uint32_t* sc_tc = ctx->r_tile_counter[slot].p;
@@ -1171,6 +1184,7 @@ int render_batch(rt_ctx* ctx, uint32_t n_frames, const float* uniforms, const rt
   if (const char* e = std::getenv("RTCORE_SHARD_GROUP")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) p.shard_group = (uint32_t)v; }
   p.shard_heads = sc_tc; p.list_count = sc_tc + rt_shard_words();
   p.block_total = p.list_count + (size_t)RT_LC_WORDS * n_frames;
+  if (two_phase) { p.shade_heads = p.block_total + (size_t)bt.bt_stride * n_frames; p.hits = ctx->r_hits[slot].p; }
   p.list = ctx->r_list[slot].p;
   p.stats = sc_st;
   p.class_hist = reinterpret_cast<uint32_t*>(sc_st + 8);        // where render_frame keeps it: single frames and batches share the history

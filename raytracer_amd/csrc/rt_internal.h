@@ -67,6 +67,8 @@ struct RtRenderParams {
   uint32_t* hit_tri;
   float*    hit_t;
   uint32_t* shard_heads;           // [rt_shard_words()] phase-B queue heads, one per 128-byte line; zeroed before launch
+  uint32_t* shade_heads;           // [rt_shard_words()] the same for the shade launch of the traverse / shade split (NULL: no split)
+  uint32_t* hits;                  // [list entries (x frames of a batch, list_stride apart)] traverse / shade split: triangle of the entry's primary hit, 0xFFFFFFFF = miss; NULL = whole pixel in one launch
   uint32_t shard_stride;           // words between shard heads
   uint32_t shard_group;            // consecutive chunks dealt to one shard at a time (round-robin over the shards)
   unsigned long long* masks;       // [3 * n_tiles] per tile and cost class: ballot of pixels whose primary ray enters the root box

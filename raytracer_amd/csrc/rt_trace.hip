@@ -430,9 +430,9 @@ RT_DEV PixelOut shade_pixel(const Scene& S, const Shade& sh, const float* U, uin
   const V3 albedo = TEX ? hit_albedo(S, hit0) : v3(1.0f, 0.84f, 0.0f);
   V3 indirect = v3(0.0f, 0.0f, 0.0f);
   if (sh.mode == RT_MODE_PT) {
-    const uint32_t GI = (uint32_t)sh.gi_samples, NB = (uint32_t)sh.gi_bounces;
+    const uint32_t GIS = (uint32_t)sh.gi_samples, NB = (uint32_t)sh.gi_bounces;
     const float pixelSeed = (float)pixelIndex / (U[36] * U[37]);
-    for (uint32_t i = 0; i < GI; ++i) {
+    for (uint32_t i = 0; i < GIS; ++i) {
       V3 throughput = albedo;
       V3 ro_b = fma3(n_os, 0.001f, hit_pos);
       V3 n_b = n_os;
@@ -454,13 +454,39 @@ RT_DEV PixelOut shade_pixel(const Scene& S, const Shade& sh, const float* U, uin
         n_b = nB;
       }
     }
-    indirect = indirect / (float)GI;
+    indirect = indirect / (float)GIS;
   }
   const float d0 = direct_radiance<LAYOUT, COUNT>(S, sh, hit_pos, n_os, light_os, pixelIndex, time_h, W, R);
   const V3 col = v3(__fmaf_rn(albedo.x, d0, indirect.x), __fmaf_rn(albedo.y, d0, indirect.y), __fmaf_rn(albedo.z, d0, indirect.z));
   const float g = 1.0f / 2.2f;
   out.rgba = unorm8(rt_pow(col.x, g)) | (unorm8(rt_pow(col.y, g)) << 8) | (unorm8(rt_pow(col.z, g)) << 16) | 0xFF000000u;
   return out;
+}
+
+// The pixel's colour from its primary hit: compute.wgsl:369-409 without the GI loop (RT_MODE_PRIMARY / SHADOW), for the shade
+// phase of the traverse / shade split.  The traversal phase left only the winning triangle's index; t, u, v come from running
+// triIntersect_fast on that one triangle again - the same function on the same inputs (primary_ray is deterministic), hence
+// the same bits the traversal held in bestT / u / v when it accepted the triangle.  That repeat is not a triangle TEST of the
+// walk and is not counted.
+template <int LAYOUT, bool COUNT, bool TEX>
+RT_DEV uint32_t shade_known_hit(const Scene& S, const Shade& sh, const float* U, uint32_t gx, uint32_t gy, uint32_t w, uint32_t h,
+                                uint32_t tri, float time_h, Work& W, RayCount& R) {
+  const PrimaryRay pr = primary_ray(U, gx, gy, w, h);
+  Hit hit0; hit0.tri = tri; hit0.steps = 0;
+  if constexpr (LAYOUT == RT_LAYOUT_WIDE64) {
+    const float4 q0 = S.tri_pre[3 * (size_t)tri + 0], q1 = S.tri_pre[3 * (size_t)tri + 1], q2 = S.tri_pre[3 * (size_t)tri + 2];
+    (void)moller_trumbore<0>(pr.ro, pr.rd, xyz(q0), xyz(q1), xyz(q2), hit0.t, hit0.u, hit0.v);
+  } else {
+    const V3 va = xyz(S.tri_pos[3 * (size_t)tri + 0]), vb = xyz(S.tri_pos[3 * (size_t)tri + 1]), vc = xyz(S.tri_pos[3 * (size_t)tri + 2]);
+    (void)moller_trumbore<0>(pr.ro, pr.rd, va, vb - va, vc - va, hit0.t, hit0.u, hit0.v);
+  }
+  const V3 hit_pos = fma3(pr.rd, hit0.t, pr.ro);
+  const V3 n_os = hit_normal(S, hit0);
+  const V3 albedo = TEX ? hit_albedo(S, hit0) : v3(1.0f, 0.84f, 0.0f);
+  const float d0 = direct_radiance<LAYOUT, COUNT>(S, sh, hit_pos, n_os, pr.light, pr.pixelIndex, time_h, W, R);
+  const V3 col = v3(__fmaf_rn(albedo.x, d0, 0.0f), __fmaf_rn(albedo.y, d0, 0.0f), __fmaf_rn(albedo.z, d0, 0.0f));   // indirect = (0,0,0), :408
+  const float g = 1.0f / 2.2f;
+  return unorm8(rt_pow(col.x, g)) | (unorm8(rt_pow(col.y, g)) << 8) | (unorm8(rt_pow(col.z, g)) << 16) | 0xFF000000u;
 }
 
 // ---- older fragment-pipeline shaders: web/shader.wgsl (V = 1) and the root shader.wgsl (V = 2) ------------
@@ -687,12 +713,14 @@ RT_DEV void flush_batch_stats(const RtRenderParams& p, uint32_t frame, int lane,
   R.primary = R.shadow = R.bounce = 0; W.box = W.tri = W.hit = W.drops = 0; pixels = 0;
 }
 // grid.x = frame: stats[frame][k] = sum over the frame's wave slots + the pixels k_cull disposed of (as k_stats_final)
-__global__ void k_stats_final_batch(const RtRenderParams p, const RtBatch bt, uint32_t n_slots, uint32_t n_inside, int count_work) {
+__global__ void k_stats_final_batch(const RtRenderParams p, const RtBatch bt, uint32_t n_slots, uint32_t n_slots_b, uint32_t n_inside, int count_work) {
   __shared__ unsigned long long s_sum[8][32];
   const uint32_t f = blockIdx.x;
   const int k = threadIdx.x & 7, part = threadIdx.x >> 3;
   unsigned long long t = 0;
   for (uint32_t b = part; b < n_slots; b += 32) t += p.stats_partial[((size_t)f * n_slots + b) * 8 + k];
+  const unsigned long long* pb = p.stats_partial + (size_t)8 * gridDim.x * n_slots;          // the shade phase's region (traverse / shade split)
+  for (uint32_t b = part; b < n_slots_b; b += 32) t += pb[((size_t)f * n_slots_b + b) * 8 + k];
   s_sum[k][part] = t;
   __syncthreads();
   if (threadIdx.x < 8) {
@@ -758,6 +786,7 @@ static int shard_stride_words() { return SHARD_STRIDE; }
 struct FrameView {
   const float* U; uint8_t* rgba8; uint32_t* hit_tri; float* hit_t; int cull_x0, cull_x1, cull_y0, cull_y1;
   unsigned long long* masks; uint32_t* block_total; uint32_t* list; uint32_t* list_count;
+  uint32_t* hits;          // traverse / shade split: per list entry the primary hit's triangle (0xFFFFFFFF = miss), this frame's own region
   bool dup;                // a batch frame whose 44 uniforms equal an earlier frame's: it shares that frame's masks / list (k_cull still writes ITS culled pixels)
 };
 template <bool BATCH, typename B>
@@ -770,9 +799,10 @@ RT_DEV FrameView frame_view(const RtRenderParams& p, const B& bt, uint32_t f) {
     const uint32_t g = r.src;                              // the frame whose cull / compaction result this one uses (itself unless a duplicate view)
     v.masks = p.masks + (size_t)g * bt.mask_stride; v.block_total = p.block_total + (size_t)g * bt.bt_stride;
     v.list = p.list + (size_t)g * bt.list_stride; v.list_count = p.list_count + (size_t)g * bt.lc_stride;
+    v.hits = p.hits ? p.hits + (size_t)f * bt.list_stride : nullptr;
     v.dup = g != f;
   } else {
-    v.dup = false;
+    v.dup = false; v.hits = p.hits;
     v.U = p.U; v.rgba8 = p.rgba8; v.hit_tri = p.hit_tri; v.hit_t = p.hit_t;
     v.cull_x0 = p.cull_x0; v.cull_x1 = p.cull_x1; v.cull_y0 = p.cull_y0; v.cull_y1 = p.cull_y1;
     v.masks = p.masks; v.block_total = p.block_total; v.list = p.list; v.list_count = p.list_count;
@@ -816,6 +846,7 @@ __global__ __launch_bounds__(TBLK) void k_cull(const RtRenderParams p, const B b
   if (blockIdx.x == 0 && blockIdx.y == 0)   // phase-B queue heads start at zero (k_render runs two launches later)
     for (uint32_t i = threadIdx.x; i < (uint32_t)(N_SHARD * SHARD_STRIDE); i += TBLK) {
       p.shard_heads[i] = 0u;
+      if (p.shade_heads) p.shade_heads[i] = 0u;
       if (p.pt_cap) { p.pt_heads[i] = 0u; if (i < (uint32_t)N_SHARD) p.pt_count[i] = 0u; }
     }
   {   // level 1: wave w traces corner w of the block's 64 tiles (0: x0 y0, 1: x7 y0, 2: x0 y7, 3: x7 y7)
@@ -1066,12 +1097,22 @@ extern "C" int rt_debug_timeline(unsigned long long* out, size_t n_words) {
 }
 #endif
 
-enum { KIND_PIXEL = 0, KIND_PTSPLIT = 1, KIND_FRAG_WEB = 2, KIND_FRAG_ROOT = 3 };   // what a lane does with its pixel
+// what a lane does with its list entry.  TRAVERSE + SHADE are the two launches RT_MODE_PRIMARY / SHADOW frames run as: the
+// primary ray's walk alone (69 - 82 VGPRs: 5 - 6 waves per SIMD instead of the 3 of the whole pixel, and the launch's time follows
+// the number of resident waves: profiles/r3/ab_occupancy_lite.txt), then the colour of the pixels that hit something
+enum { KIND_PIXEL = 0, KIND_PTSPLIT = 1, KIND_FRAG_WEB = 2, KIND_FRAG_ROOT = 3, KIND_TRAVERSE = 4, KIND_SHADE = 5 };
 template <int LAYOUT, bool COUNT, bool TEX, int KIND, bool BATCH = false, typename B = RtNoBatch>
 __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p, const B bt) {
   constexpr bool PTSPLIT = KIND == KIND_PTSPLIT;
-  static_assert(!BATCH || KIND == KIND_PIXEL, "a batch runs the compute.wgsl pixel kind only");
+  constexpr bool SHADE = KIND == KIND_SHADE;
+  static_assert(!BATCH || KIND == KIND_PIXEL || KIND == KIND_TRAVERSE || KIND == KIND_SHADE, "a batch runs the compute.wgsl pixel kind only");
   constexpr int RPL = (RT_MAX_BATCH * N_CLASS + 63) / 64;   // runs (frame x cost class) of a batch's run table per lane
+  constexpr int N_RUN = RPL * 64;
+  // A work item of the queue: 64 list entries - one per lane - for every kind but SHADE.  The shade launch takes SHADE_G x 64
+  // consecutive entries of one run, keeps those whose primary ray hit something (about a quarter of cfg 3's list) in a
+  // per-wave LDS queue and colours them 64 at a time: lanes = hit pixels, not list entries.
+  constexpr uint32_t SHADE_G = 8;
+  constexpr uint32_t ITEM = SHADE ? 64u * SHADE_G : 64u;
   extern __shared__ __align__(16) unsigned char smem[];
 #ifdef RT_TIMELINE
   const unsigned long long tl_start = wall_clock64();
@@ -1101,42 +1142,53 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p, const B
   for (int c = 2; c < N_CLASS; ++c) class_thr[c] = p.pix_class ? p.list_count[c] : 0xFFFFFFFFu;
   __shared__ uint32_t s_hist[64];                        // this block's step histogram of non-cheap pixels (next frame's threshold)
   if (threadIdx.x < 64) s_hist[threadIdx.x] = 0u;
-  __syncthreads();
   // The chunk space.  One frame: the list's 64-pixel chunks, front to back.  A batch: the runs (class, frame) of all the
-  // frames' lists, hottest class of EVERY frame first (class-major, frame-minor), each run cut into its own chunks; lane o
-  // holds run o's first chunk, and a chunk id finds its run with one ballot.
+  // frames' lists, hottest class of EVERY frame first (class-major, frame-minor), each run cut into its own chunks.  The
+  // run table (first chunk, list start, entries, frame of every run) lives in LDS, one copy per block, built by wave 0
+  // (until round 3 every lane held two runs in eight registers for the whole launch: registers are this kernel's occupancy);
+  // a chunk id finds its run with one ballot per 64 runs over the runs' first chunks.
   uint32_t n_list = 0, n_chunks = 0;
-  uint32_t seg_first[RPL], seg_start[RPL], seg_count[RPL], seg_frame[RPL];   // BATCH: my runs (run r * 64 + lane = class rank * n + frame)
-#pragma unroll
-  for (int r = 0; r < RPL; ++r) { seg_first[r] = 0xFFFFFFFFu; seg_start[r] = seg_count[r] = seg_frame[r] = 0u; }
+  const uint32_t *seg_first_p = nullptr, *seg_start_p = nullptr, *seg_count_p = nullptr, *seg_frame_p = nullptr;
   if constexpr (!BATCH) {
     n_list = *p.list_count;                              // written by k_compact (previous launch on this stream)
-    n_chunks = (n_list + 63u) / 64u;
+    n_chunks = (n_list + ITEM - 1u) / ITEM;
+    __syncthreads();
   } else {
-    const uint32_t n_seg = bt.n * (uint32_t)N_CLASS;
+    __shared__ uint32_t s_first[N_RUN], s_start[N_RUN], s_count[N_RUN], s_frame[N_RUN], s_total;
+    if (threadIdx.x < 64) {
+      const uint32_t n_seg = bt.n * (uint32_t)N_CLASS;
+      uint32_t total = 0;
 #pragma unroll
-    for (int r = 0; r < RPL; ++r) {
-      const uint32_t run = (uint32_t)r * 64u + (uint32_t)lane;
-      uint32_t my_chunks = 0;
-      if (run < n_seg) {
-        seg_frame[r] = run % bt.n;
-        const uint32_t c = (uint32_t)(N_CLASS - 1) - run / bt.n;                        // hottest class first, cheap / unknown (0) last
-        const uint32_t* lc = p.list_count + (size_t)bt.frames[seg_frame[r]].src * bt.lc_stride;
-        seg_start[r] = lc[8 + c]; seg_count[r] = lc[16 + c];
-        my_chunks = (seg_count[r] + 63u) / 64u;
+      for (int r = 0; r < RPL; ++r) {
+        const uint32_t run = (uint32_t)r * 64u + (uint32_t)lane;
+        uint32_t my_chunks = 0, frame = 0, start = 0, count = 0;
+        if (run < n_seg) {
+          frame = run % bt.n;
+          const uint32_t c = (uint32_t)(N_CLASS - 1) - run / bt.n;                        // hottest class first, cheap / unknown (0) last
+          const uint32_t* lc = p.list_count + (size_t)bt.frames[frame].src * bt.lc_stride;
+          start = lc[8 + c]; count = lc[16 + c];
+          my_chunks = (count + ITEM - 1u) / ITEM;
+        }
+        uint32_t inc = my_chunks;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, o); if (lane >= o) inc += t; }
+        s_first[run] = (run < n_seg && my_chunks > 0u) ? total + inc - my_chunks : 0xFFFFFFFFu;   // empty runs never match
+        s_start[run] = start; s_count[run] = count; s_frame[run] = frame;
+        total += (uint32_t)__shfl((int)inc, 63);
       }
-      uint32_t inc = my_chunks;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)inc, o); if (lane >= o) inc += t; }
-      seg_first[r] = (run < n_seg && my_chunks > 0u) ? n_chunks + inc - my_chunks : 0xFFFFFFFFu;   // empty runs never match
-      n_chunks += (uint32_t)__shfl((int)inc, 63);
+      if (lane == 0) s_total = total;
     }
+    __syncthreads();
+    n_chunks = s_total;
+    // (closures below read the table through these)
+    seg_first_p = s_first; seg_start_p = s_start; seg_count_p = s_count; seg_frame_p = s_frame;
   }
+  uint32_t* const heads = SHADE ? p.shade_heads : p.shard_heads;
   const uint32_t per_xcd = (gridDim.x + 7u) / 8u;
   int shard = (int)((blockIdx.x & 7u) * (N_SHARD / 8) + ((blockIdx.x >> 3) * (N_SHARD / 8)) / per_xcd) & (N_SHARD - 1);
   for (uint32_t scans = 0; scans <= 4u * N_SHARD; ++scans) {          // every wave reaches the exit: a scan that finds nothing
     // lane l looks after shard l
-    const uint32_t head = __hip_atomic_load(p.shard_heads + (size_t)lane * p.shard_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t head = __hip_atomic_load(heads + (size_t)lane * p.shard_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long avail = __ballot(shard_chunk((uint32_t)lane, head, p.shard_group) < n_chunks);
     if (!avail) break;
     // first non-empty shard at or after `shard` (rotating)
@@ -1144,7 +1196,7 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p, const B
     shard = (shard + (__ffsll((long long)rot) - 1)) & (N_SHARD - 1);
     for (;;) {
       uint32_t h = 0;
-      if (lane == 0) h = atomicAdd(p.shard_heads + (size_t)shard * p.shard_stride, 1u);
+      if (lane == 0) h = atomicAdd(heads + (size_t)shard * p.shard_stride, 1u);
       const uint32_t chunk = shard_chunk((uint32_t)shard, (uint32_t)__builtin_amdgcn_readfirstlane((int)h), p.shard_group);
       if (chunk >= n_chunks) break;
 #ifdef RT_TIMELINE
@@ -1155,20 +1207,19 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p, const B
       uint32_t li, li_end;
       bool last_frame = true;
       uint32_t batch_frame = 0;
-      if constexpr (!BATCH) { li = chunk * 64u + (uint32_t)lane; li_end = n_list; }
+      if constexpr (!BATCH) { li = chunk * ITEM + (uint32_t)lane; li_end = n_list; }
       else {
         // the last run that starts at or before this chunk (empty runs never match); chunk is wave-uniform, so are the branches
-        uint32_t my_frame = seg_frame[0], my_first = seg_first[0], my_start = seg_start[0], my_count = seg_count[0];
-        int o = 63 - __clzll((long long)__ballot(seg_first[0] <= chunk));
+        int o = 0;
 #pragma unroll
-        for (int r = 1; r < RPL; ++r) {
-          const unsigned long long m = __ballot(seg_first[r] <= chunk);
-          if (m) { o = 63 - __clzll((long long)m); my_frame = seg_frame[r]; my_first = seg_first[r]; my_start = seg_start[r]; my_count = seg_count[r]; }
+        for (int r = 0; r < RPL; ++r) {
+          const unsigned long long m = __ballot(seg_first_p[r * 64 + lane] <= chunk);
+          if (m) o = r * 64 + 63 - __clzll((long long)m);
         }
-        const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)my_frame, o));
-        const uint32_t first = (uint32_t)__shfl((int)my_first, o), start = (uint32_t)__shfl((int)my_start, o), cnt = (uint32_t)__shfl((int)my_count, o);
+        o = __builtin_amdgcn_readfirstlane(o);
+        const uint32_t f = seg_frame_p[o], first = seg_first_p[o], start = seg_start_p[o], cnt = seg_count_p[o];
         fv = frame_view<true>(p, bt, f);
-        li = start + (chunk - first) * 64u + (uint32_t)lane; li_end = start + cnt;
+        li = start + (chunk - first) * ITEM + (uint32_t)lane; li_end = start + cnt;
         time_h = (float)hash_u32(sat_u32(fv.U[38]));
         last_frame = f + 1u == bt.n;
         batch_frame = f;
@@ -1176,6 +1227,37 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p, const B
       if constexpr (BATCH && COUNT) {                       // counters are per frame: hand over what the previous chunk's frame collected
         if (cur_frame != 0xFFFFFFFFu && cur_frame != batch_frame) flush_batch_stats(p, cur_frame, lane, R, W, pixels);
         cur_frame = batch_frame;
+      }
+      if constexpr (SHADE) {
+        __shared__ uint32_t s_queue[TBLK / 64][2 * 64 * SHADE_G];          // per wave: (list entry, triangle) of the item's hits
+        uint32_t* q = s_queue[threadIdx.x >> 6];
+        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        uint32_t tri_j[SHADE_G];
+#pragma unroll
+        for (uint32_t j = 0; j < SHADE_G; ++j) { const uint32_t e = li + 64u * j; tri_j[j] = e < li_end ? fv.hits[e] : 0xFFFFFFFFu; }
+        uint32_t n_hit = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < SHADE_G; ++j) {
+          const bool is_hit = tri_j[j] != 0xFFFFFFFFu;
+          const unsigned long long m = __ballot(is_hit);
+          if (is_hit) { const uint32_t pos = n_hit + (uint32_t)__popcll(m & lt); q[2 * pos] = li + 64u * j; q[2 * pos + 1] = tri_j[j]; }
+          n_hit += (uint32_t)__popcll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t k0 = 0; k0 < n_hit; k0 += 64u) {
+          const uint32_t k = k0 + (uint32_t)lane;
+          if (k < n_hit) {
+            const uint32_t e = q[2 * k], tri = q[2 * k + 1];
+            const uint32_t idx = fv.list[e];
+            const uint32_t x = idx % p.width, y = local_to_global_row(p, idx / p.width);
+            const uint32_t rgba = shade_known_hit<LAYOUT, COUNT, TEX>(S, sh, fv.U, x, y, p.width, p.height, tri, time_h, W, R);
+            if (fv.rgba8) reinterpret_cast<uint32_t*>(fv.rgba8)[idx] = rgba;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();                              // the queue is rewritten by the wave's next item
+        continue;
       }
       PtRec rec;
       bool rec_hit = false;
@@ -1185,10 +1267,21 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p, const B
         const uint32_t y = local_to_global_row(p, lrow);
         PixelOut o;
         if constexpr (PTSPLIT) { o = shade_pt_primary<LAYOUT, COUNT, TEX>(S, sh, fv.U, x, y, p.width, p.height, time_h, W, R, rec, rec_hit); rec.idx = idx; }
+        else if constexpr (KIND == KIND_TRAVERSE) {
+          const PrimaryRay pr = primary_ray(fv.U, x, y, p.width, p.height);
+          R.primary += 1;
+          const Hit h0 = closest<LAYOUT, COUNT>(S, pr.ro, pr.rd, pr.inv, 1e20f, W);
+          const bool miss = h0.t >= 1e19f;
+          o.rgba = 0xFF000000u; o.tri = miss ? 0xFFFFFFFFu : h0.tri; o.t = h0.t; o.cost = h0.steps;   // a miss is final: (0,0,0,1), :365-367
+          fv.hits[li] = o.tri;                                  // the shade phase colours the hits
+          rec_hit = !miss;
+        }
+
         else if constexpr (KIND == KIND_FRAG_WEB) o = shade_frag<COUNT, 1>(S, sh, fv.U, x, y, p.width, p.height, p.miss_rgba, W, R);
         else if constexpr (KIND == KIND_FRAG_ROOT) o = shade_frag<COUNT, 2>(S, sh, fv.U, x, y, p.width, p.height, p.miss_rgba, W, R);
         else o = shade_pixel<LAYOUT, COUNT, TEX>(S, sh, fv.U, x, y, p.width, p.height, time_h, W, R);
-        if (fv.rgba8 && !rec_hit) reinterpret_cast<uint32_t*>(fv.rgba8)[idx] = o.rgba;     // a PT hit pixel gets its colour in part 2
+        {
+        if (fv.rgba8 && !rec_hit) reinterpret_cast<uint32_t*>(fv.rgba8)[idx] = o.rgba;     // a hit pixel gets its colour in part 2 (PT split, traverse / shade split)
         if (fv.hit_tri) fv.hit_tri[idx] = o.tri;
         if (fv.hit_t) fv.hit_t[idx] = o.t;
         if (p.pix_class && last_frame) {                  // a batch leaves the hints of its last frame
@@ -1199,6 +1292,7 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p, const B
           if (o.cost >= p.class_t1) atomicAdd(&s_hist[min((o.cost - p.class_t1) >> 2, 63u)], 1u);
         }
         pixels += 1;
+        }
       }
       if constexpr (PTSPLIT) {                              // append the chunk's hit records to the sub-list of its shard: one atomic per chunk
         const unsigned long long hm = __ballot(rec_hit);
@@ -1225,7 +1319,7 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p, const B
 #endif
   if constexpr (!BATCH) flush_stats<COUNT>(p, lane, R, W, pixels);
   else if constexpr (COUNT) { if (cur_frame != 0xFFFFFFFFu) flush_batch_stats(p, cur_frame, lane, R, W, pixels); }   // a batch keeps statistics only when asked to count
-  if (p.pix_class) {                                     // 64 bins, one atomic per non-empty bin and block, spread over the launch's tail
+  if (!SHADE && p.pix_class) {                           // 64 bins, one atomic per non-empty bin and block, spread over the launch's tail
     __syncthreads();
     if (threadIdx.x < 64 && s_hist[threadIdx.x]) atomicAdd(&p.class_hist[threadIdx.x], s_hist[threadIdx.x]);
   }
@@ -1381,7 +1475,7 @@ __global__ __launch_bounds__(TBLK) void k_assemble(const uint32_t* __restrict__ 
 // Persistent grid of phase B: what is actually resident (occupancy query), so that no block starts
 // late behind another one (measured: with a 4-blocks/CU grid and 3 resident, a quarter of the
 // waves started 400 us into a 650 us launch).
-uint32_t rt_render_grid(int n_cu) { return (uint32_t)n_cu * 8u; }   // upper bound (sizes the per-block stats slots: two launches with the PT split)
+uint32_t rt_render_grid(int n_cu) { return (uint32_t)n_cu * 16u; }   // upper bound (sizes the per-block stats slots: two launches with the PT split)
 // The k_render instantiation a frame runs.  Every launch and every occupancy query goes through this one table, so the
 // persistent grid is sized from the kernel that is actually launched (COUNT = false variants hold fewer registers).
 template <int L, bool C, bool X, int K, bool BT>
@@ -1403,9 +1497,11 @@ static const void* render_kernel(int layout, bool count, bool tex, int kind, boo
   if (kind == KIND_FRAG_WEB) return count ? render_kernel_ptr<RT_LAYOUT_WIDE64, true, false, KIND_FRAG_WEB, false>() : render_kernel_ptr<RT_LAYOUT_WIDE64, false, false, KIND_FRAG_WEB, false>();
   if (kind == KIND_FRAG_ROOT) return count ? render_kernel_ptr<RT_LAYOUT_WIDE64, true, false, KIND_FRAG_ROOT, false>() : render_kernel_ptr<RT_LAYOUT_WIDE64, false, false, KIND_FRAG_ROOT, false>();
   if (kind == KIND_PTSPLIT) return render_kernel_lcx<KIND_PTSPLIT, false>(layout, count, tex);
+  if (kind == KIND_TRAVERSE) return batch ? render_kernel_lcx<KIND_TRAVERSE, true>(layout, count, false) : render_kernel_lcx<KIND_TRAVERSE, false>(layout, count, false);
+  if (kind == KIND_SHADE) return batch ? render_kernel_lcx<KIND_SHADE, true>(layout, count, tex) : render_kernel_lcx<KIND_SHADE, false>(layout, count, tex);
   return batch ? render_kernel_lcx<KIND_PIXEL, true>(layout, count, tex) : render_kernel_lcx<KIND_PIXEL, false>(layout, count, tex);
 }
-static uint32_t resident_grid(int n_cu, int max_stack, const void* kernel) {
+static uint32_t resident_grid(int n_cu, int max_stack, const void* kernel, int cap = 0, const char* env = "RTCORE_BLOCKS_PER_CU") {
   struct Slot { const void* k; int stack; int per_cu; };
   static Slot slots[64];
   static int n_slots = 0;
@@ -1418,11 +1514,12 @@ static uint32_t resident_grid(int n_cu, int max_stack, const void* kernel) {
     const size_t lds = (size_t)max_stack * TBLK * 8;
     const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, TBLK, lds);
     if (e != hipSuccess || nb < 1) nb = 2;
-    per_cu = nb > 4 ? 4 : nb;
-    if (const char* e = getenv("RTCORE_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= per_cu) per_cu = v; }
+    per_cu = nb > 6 ? 6 : nb;
     if (n_slots < 64) slots[n_slots++] = Slot{kernel, max_stack, per_cu};
   }
-  return (uint32_t)n_cu * (uint32_t)per_cu;
+  int want = (cap > 0 && cap < per_cu) ? cap : per_cu;      // per_cu = what is resident: never more than that
+  if (const char* e = getenv(env)) { const int v = atoi(e); if (v >= 1) want = v < per_cu ? v : per_cu; }   // (experiments: read on every launch; may lift a cap)
+  return (uint32_t)n_cu * (uint32_t)want;
 }
 uint32_t rt_cull_blocks(uint32_t n_tiles) { return (n_tiles + CULL_TPB - 1) / CULL_TPB; }
 uint32_t rt_n_class() { return (uint32_t)N_CLASS; }
@@ -1490,8 +1587,12 @@ void rt_launch_render(const RtRenderParams& p_in, int layout, bool count_work, b
   const bool tex = p.tri_uv != nullptr, split = p.pt_cap != 0;
   const int kind = p.frag == 1 ? KIND_FRAG_WEB : p.frag == 2 ? KIND_FRAG_ROOT : split ? KIND_PTSPLIT : KIND_PIXEL;
   if (p.frag) layout = RT_LAYOUT_WIDE64;
-  const void* kernel = render_kernel(layout, count_work, tex && !p.frag, kind, false);
-  p.render_blocks = resident_grid(n_cu, p.max_stack, kernel);
+  // RT_MODE_PRIMARY / SHADOW with a hit buffer: two launches, the primary rays' walk and the colour of the hits
+  const bool two_phase = p.hits != nullptr && kind == KIND_PIXEL && p.mode != RT_MODE_PT;
+  const void* kernel = two_phase ? render_kernel(layout, count_work, false, KIND_TRAVERSE, false) : render_kernel(layout, count_work, tex && !p.frag, kind, false);
+  // one frame per launch: more resident waves stretch the tail (every chain of dependent fetches gets slower) and lose what
+  // they hide; 3 blocks per CU stay the default there (profiles/r3/ab_two_phase.txt), a batch takes all that fit
+  p.render_blocks = resident_grid(n_cu, p.max_stack, kernel, two_phase ? 3 : 0, two_phase ? "RTCORE_TRAVERSE_BPC" : "RTCORE_BLOCKS_PER_CU");
   // A persistent grid that fills the chip leaves a frame queued behind it nothing but its tail to overlap with.  Frames
   // in flight therefore take 2 of the (usually 3) resident blocks per CU each, so that two of them really run side by
   // side (cfg 3, two in flight: 0.440 -> 0.400 ms per frame; a 1/8 stripe share, three in flight: 0.146 -> 0.125 ms).
@@ -1505,6 +1606,16 @@ void rt_launch_render(const RtRenderParams& p_in, int layout, bool count_work, b
   if (ev0) (void)hipEventRecord(ev0, s);
   void* args[2] = {&p, &nb};
   (void)hipLaunchKernel(kernel, g, b, args, lds, s);
+  uint32_t stat_blocks = split ? 2u * g.x : g.x;
+  if (two_phase) {
+    const void* shade = render_kernel(layout, count_work, tex, KIND_SHADE, false);
+    RtRenderParams p2 = p;
+    p2.render_blocks = resident_grid(n_cu, 0, shade, 4, "RTCORE_SHADE_BPC");
+    p2.stats_partial = p.stats_partial + (size_t)g.x * 8;
+    void* args2[2] = {&p2, &nb};
+    (void)hipLaunchKernel(shade, dim3(p2.render_blocks), b, args2, 0, s);
+    stat_blocks = g.x + p2.render_blocks;
+  }
   if (split) {   // PT split: part 1 (KIND_PTSPLIT) then part 2 (k_pt_samples) with its own rows of the per-block stats partials
     RtRenderParams p2 = p;
     p2.stats_partial = p.stats_partial + (size_t)g.x * 8;
@@ -1520,7 +1631,7 @@ void rt_launch_render(const RtRenderParams& p_in, int layout, bool count_work, b
     hipLaunchKernelGGL(k_pt_resolve, dim3((p.pt_cap + TBLK - 1) / TBLK, N_SHARD), b, 0, s, p);
   }
   if (ev1) (void)hipEventRecord(ev1, s);
-  if (want_stats) hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(256), 0, s, p, split ? 2u * g.x : g.x, p.local_rows * p.width, count_work ? 1 : 0);
+  if (want_stats) hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(256), 0, s, p, stat_blocks, p.local_rows * p.width, count_work ? 1 : 0);
 }
 
 // A batch: the frames' cull / scan / compact passes as one grid dimension of three launches, then ONE persistent k_render over all
@@ -1530,19 +1641,37 @@ void rt_launch_render_batch(const RtRenderParams& p_in, const RtBatch& bt, int l
   RtRenderParams p = p_in;
   RtBatch batch = bt;
   const dim3 b(TBLK), gc(rt_cull_blocks(p.n_tiles), bt.n);
-  const void* kernel = render_kernel(layout, count_work, p.tri_uv != nullptr, KIND_PIXEL, true);
-  p.render_blocks = resident_grid(n_cu, p.max_stack, kernel);
+  const bool tex = p.tri_uv != nullptr;
+  const bool two_phase = p.hits != nullptr && p.mode != RT_MODE_PT;      // as rt_launch_render
+  const void* kernel = two_phase ? render_kernel(layout, count_work, false, KIND_TRAVERSE, true) : render_kernel(layout, count_work, tex, KIND_PIXEL, true);
+  // the traversal launch: 5 blocks per CU (of the 6 that fit) - 4 / 5 / 6: 0.254 / 0.234 / 0.239 ms per frame with the shade launch at 4
+  p.render_blocks = resident_grid(n_cu, p.max_stack, kernel, two_phase ? 5 : 0, two_phase ? "RTCORE_TRAVERSE_BPC" : "RTCORE_BLOCKS_PER_CU");
   if (p.blocks_per_cu_cap && !getenv("RTCORE_BLOCKS_PER_CU")) p.render_blocks = std::min(p.render_blocks, (uint32_t)n_cu * p.blocks_per_cu_cap);   // pipelines in flight share the CUs
   hipLaunchKernelGGL((k_cull<true, RtBatch>), gc, b, 0, s, p, batch);
   hipLaunchKernelGGL((k_scan<true, RtBatch>), dim3(bt.n), b, 0, s, p, batch);
   hipLaunchKernelGGL((k_compact<true, RtBatch>), gc, b, 0, s, p, batch);
   const size_t lds = (size_t)p.max_stack * TBLK * (sizeof(uint32_t) + sizeof(float));
+  const uint32_t slots_a = p.render_blocks * (TBLK / 64);
+  uint32_t slots_b = 0;
+  RtRenderParams p2 = p;
+  const void* shade = nullptr;
+  if (two_phase) {
+    shade = render_kernel(layout, count_work, tex, KIND_SHADE, true);
+    p2.render_blocks = resident_grid(n_cu, 0, shade, 4, "RTCORE_SHADE_BPC");
+    if (p.blocks_per_cu_cap && !getenv("RTCORE_SHADE_BPC")) p2.render_blocks = std::min(p2.render_blocks, (uint32_t)n_cu * p.blocks_per_cu_cap);
+    slots_b = p2.render_blocks * (TBLK / 64);
+    p2.stats_partial = p.stats_partial ? p.stats_partial + (size_t)8 * bt.n * slots_a : nullptr;   // the shade phase's wave slots lie behind the traversal's
+  }
+  if (count_work) (void)hipMemsetAsync(p.stats_partial, 0, sizeof(unsigned long long) * 8 * (size_t)bt.n * (slots_a + slots_b), s);
   if (ev0) (void)hipEventRecord(ev0, s);
   void* args[2] = {&p, &batch};
-  if (count_work) (void)hipMemsetAsync(p.stats_partial, 0, sizeof(unsigned long long) * 8 * (size_t)bt.n * p.render_blocks * (TBLK / 64), s);
   (void)hipLaunchKernel(kernel, dim3(p.render_blocks), b, args, lds, s);
+  if (two_phase) {
+    void* args2[2] = {&p2, &batch};
+    (void)hipLaunchKernel(shade, dim3(p2.render_blocks), b, args2, 0, s);
+  }
   if (ev1) (void)hipEventRecord(ev1, s);
-  if (count_work) hipLaunchKernelGGL(k_stats_final_batch, dim3(bt.n), dim3(256), 0, s, p, batch, p.render_blocks * (TBLK / 64), p.local_rows * p.width, 1);
+  if (count_work) hipLaunchKernelGGL(k_stats_final_batch, dim3(bt.n), dim3(256), 0, s, p, batch, slots_a, slots_b, p.local_rows * p.width, 1);
 }
 
 void rt_launch_gather_uv(const float* texcoords, const uint32_t* tex_idx, const int32_t* material_ids, const uint32_t* order,

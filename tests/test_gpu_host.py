@@ -121,4 +121,4 @@ def test_bench_runs_a_mesh_file_with_its_mtl_and_textures(tmp_path, plane_obj_pa
     w = lines["tex"]["config"]["workload"]
     assert "plane.obj" in w and "standin_checker_0.rgb" in w and "standin_checker_1.rgb" in w and "6298 triangles" in w
     assert "constant albedo" in lines["plain"]["config"]["workload"]
-    assert lines["tex"]["value"] > 0 and lines["tex"]["config"]["rays_per_frame"] == lines["plain"]["config"]["rays_per_frame"]
+    assert lines["tex"]["value"] > 0 and lines["tex"]["config"]["rays_traced_per_frame"] == lines["plain"]["config"]["rays_traced_per_frame"]
