@@ -212,15 +212,19 @@ def main():
 
     # Rays and work counters of the n frames of a loop (this rank's share), from the kernels' OWN counters of exactly the
     # pipelines the loop runs: the same batches once more with RT_FLAG_COUNT_WORK (rt_batch_stats), untimed.
-    copts = rt.render_opts(mode=mode, layout=layout, flags=rt.FLAG_COUNT_WORK | tflag, **shade,
-                           stripe_rows=frame.opts.stripe_rows, stripe_rank=rank, stripe_world=world)
+    copts_full = rt.render_opts(mode=mode, layout=layout, flags=rt.FLAG_COUNT_WORK | tflag, **shade,
+                                stripe_rows=frame.opts.stripe_rows, stripe_rank=rank, stripe_world=world)
     scratch_img = torch.zeros((batch, frame.rpr if world > 1 else H, W), dtype=torch.int32, device=device)
 
-    def counted(vs, n, per_frame=False):
+    popts = rt.render_opts(mode=rt.MODE_PRIMARY, layout=layout, flags=rt.FLAG_COUNT_WORK | tflag, **shade,
+                           stripe_rows=frame.opts.stripe_rows, stripe_rank=rank, stripe_world=world)
+
+    def counted(vs, n, per_frame=False, primary_only=False):
         """-> per frame (rays as the reference's loop casts them, rays that enter the tree, SURVEY 8d bytes of the whole frame,
         k_render's own bytes), and the counting kernels' average launch time.  Pixels whose primary ray misses the root box never
         reach k_render (k_cull disposes of them): each is one ray + one box test + one pixel, and those 36 B are NOT k_render's."""
         per = []
+        copts = popts if primary_only else copts_full
         ctx.profile_begin()
         if bframes is None or per_frame:
             sts = [ctx.render_device(vs[i % len(vs)], copts, d_rgba8=scratch_img[0].data_ptr()) for i in range(n)]
@@ -239,10 +243,12 @@ def main():
             per.append((rays, rays - culled, fb, fb - 36 * culled))
         return per, cms
 
-    if bframes is not None:             # set-up (untimed): the first full batch sizes the pipeline's scratch
-        bframes.step(np.stack([view(k) for k in range(batch)]))
+    if bframes is not None:             # set-up (untimed): one pipeline of the largest size the loop uses sizes the scratch
+        bframes.step(np.stack([view(k) for k in range(max(rdist.batch_sizes(K, batch)))]))
         bframes.finish()
-    run_frames(views, args.warmup)
+    # warm-up: W steps - in whole pipelines of the timed loop's shape when frames are batched, so that every launch of the traversal
+    # kernel in a run has the timed launches' size (rocprofv3's per-kernel average is then the average of like launches)
+    run_frames(views, args.warmup if bframes is None else -(-args.warmup // K) * K)
 
     def fence():
         frame.finish()
@@ -262,14 +268,19 @@ def main():
         run_frames(vs, n, per_frame)
         fence()
         e = time.perf_counter() - t0
-        pipe_ms, trav_ms, launches = ctx.profile_end()     # per launch: frame pipeline (cull, scan, compact, traversal) / k_render alone
-        return e, pipe_ms, trav_ms, launches
+        # per pipeline: all its kernels (cull, scan, compact, traversal) / the traversal launch / the shade launch (0 unless split)
+        pipe_ms, trav_ms, shade_ms, launches = ctx.profile_end_phases()
+        return e, pipe_ms, trav_ms, shade_ms, launches
 
-    elapsed, kernel_ms, trav_ms, n_launch = timed(views, K)
+    elapsed, kernel_ms, trav_ms, shade_ms, n_launch = timed(views, K)
     frames_per_launch = K / max(n_launch, 1)               # 1, or the mean batch size (a k_render launch then walks that many frames' lists)
     per, counted_ms = counted(views, K)
     my_rays, my_rays_traced = sum(p[0] for p in per), sum(p[1] for p in per)
     my_frame_bytes, my_bytes = sum(p[2] for p in per), sum(p[3] for p in per)
+    # RT_MODE_SHADOW pipelines of a batch run as two launches: the walk of the primary rays (exactly RT_MODE_PRIMARY's box / triangle /
+    # hit counters) and the shade launch (the shadow rays' box tests): the first one's own algorithmic bytes from a primary-only count
+    split = bframes is not None and mode == rt.MODE_SHADOW and shade_ms > 0.0
+    trav_bytes = sum(p[3] for p in counted(views, K, primary_only=True)[0]) if split else my_bytes
 
     # N > 1: the frame rank 0 assembled from all ranks' stripes (the last timed one) against rank 0's own render of the whole
     # frame — outside the timed region; says on the driver's 8-GPU run that the exchange delivered the right pixels
@@ -295,12 +306,12 @@ def main():
     if world == 1 and not args.no_legs:
         def leg(vs, per_frame):
             run_frames(vs, max(args.warmup, batch if not per_frame else 3), per_frame)
-            e, _, tr_ms, launches = timed(vs, K, per_frame)
+            e, _, tr_ms, sh_ms, launches = timed(vs, K, per_frame)
             pr, _ = counted(vs, K, per_frame)
             traced, byts = sum(p[1] for p in pr), sum(p[3] for p in pr)
             return {"value": round(traced / e / 1e6, 2), "unit": "Mrays/s", "value_all_pixels": round(sum(p[0] for p in pr) / e / 1e6, 2),
-                    "ms_per_step": round(e / K * 1e3, 4), "kernel_ms": round(tr_ms, 4), "frames_per_launch": round(K / max(launches, 1), 3),
-                    "algorithmic_gbs": round(byts / (tr_ms * launches * 1e-3) / 1e9, 1) if tr_ms > 0 else None}
+                    "ms_per_step": round(e / K * 1e3, 4), "kernel_ms": round(tr_ms + sh_ms, 4), "frames_per_launch": round(K / max(launches, 1), 3),
+                    "algorithmic_gbs": round(byts / ((tr_ms + sh_ms) * launches * 1e-3) / 1e9, 1) if tr_ms > 0 else None}
         if batch > 1:
             legs["per_frame"] = leg(views, True)
             legs["per_frame"]["what"] = ("the same camera path, ONE frame per pipeline (rt_render_device, one frame in flight): the latency-bound loop of "
@@ -325,7 +336,7 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / K * 1e3
         value = total_traced / elapsed / 1e6
-        launch_bytes = my_bytes / max(n_launch, 1)         # this rank's algorithmic bytes per k_render launch
+        launch_bytes = trav_bytes / max(n_launch, 1)       # this rank's algorithmic bytes per launch of the traversal kernel
         what = {"primary": "primary rays only", "shadow": "primary + 4 soft shadow rays",
                 "pt": f"full computeLighting_optimized: GI {args.spp} spp x 3 bounces + 4 soft shadow rays per vertex",
                 "frag-web": "web/shader.wgsl computeLighting_optimized: GI 32 x 3 bounces, 8-tap Poisson-disk light per vertex",
@@ -358,7 +369,7 @@ def main():
             "bvh_broadcast_ms": round(bcast_ms, 3),
             "frame_kernels_ms": round(kernel_ms, 4), "frame_kernels_ms_max_rank": round(kernel_max, 4),
             "roofline": roofline(args, world, textured, batch, frames_per_launch, trav_ms, launch_bytes, counted_ms,
-                                 int(my_frame_bytes - my_bytes) // max(n_launch, 1)),
+                                 int(my_frame_bytes - my_bytes) // max(n_launch, 1), shade_ms, int(my_bytes - trav_bytes) // max(n_launch, 1)),
         }
         if "per_frame" in legs:
             out["value_per_frame"] = legs["per_frame"]["value"]      # one frame per pipeline: comparable with round 1's loop
@@ -403,7 +414,7 @@ def cfg3_textures():
 L2_PEAK_GBS, IC_PEAK_GBS = 34500.0, 8600.0
 
 
-def roofline(args, world, textured, batch, frames_per_launch, trav_ms, launch_bytes, counted_ms, bytes_outside):
+def roofline(args, world, textured, batch, frames_per_launch, trav_ms, launch_bytes, counted_ms, bytes_outside, shade_ms=0.0, shade_bytes=0):
     """The traversal kernel against the memory level that serves its bytes.  Time: the kernel's average launch duration over
     exactly the timed steps (hipEvents on its own stream).  Bytes per level: PMC counters of the same command, collected by
     rocprofv3 runs of their own (scripts/pmc_passes.sh -> scripts/pmc_summary.py -> profiles/traffic.json, committed), per frame
@@ -418,9 +429,12 @@ def roofline(args, world, textured, batch, frames_per_launch, trav_ms, launch_by
     Without a collection for this exact workload the levels are unknown: the algorithmic bytes are then priced against the L2
     peak (every one of them crosses L1 <- L2 at most once) and `traffic` is null."""
     t = trav_ms * 1e-3
-    r = {"kernel": "k_render", "kernel_ms": round(trav_ms, 4), "frames_per_launch": round(frames_per_launch, 3),
+    r = {"kernel": "k_render<KIND_TRAVERSE> (the primary rays' walk; the shade launch behind it is `shade_*`)" if shade_ms > 0 else "k_render",
+         "kernel_ms": round(trav_ms, 4), "frames_per_launch": round(frames_per_launch, 3),
          "algorithmic_bytes_per_launch": int(launch_bytes), "algorithmic_gbs": round(launch_bytes / t / 1e9, 1) if t > 0 else None,
          "bytes_outside_kernel_per_launch": int(bytes_outside), "kernel_ms_counting": round(counted_ms, 4)}
+    if shade_ms > 0:
+        r["shade_kernel_ms"], r["shade_algorithmic_bytes_per_launch"] = round(shade_ms, 4), int(shade_bytes)
     pmc = pmc_levels(args, world, textured, batch)
     if not pmc or t <= 0:
         ach = launch_bytes / t / 1e9 if t > 0 else 0.0
@@ -438,11 +452,13 @@ def roofline(args, world, textured, batch, frames_per_launch, trav_ms, launch_by
               "peak": levels[bound]["peak"], "unit": "GB/s", "frac": levels[bound]["frac"],
               "traffic": levels["fabric"]["bytes_per_launch"], "levels": levels,
               "l2_hit_rate": pmc.get("l2_hit_rate"), "valu_lane_util": pmc.get("valu_lane_util"), "ta_busy": pmc.get("ta_busy"),
+              "valu_busy": pmc.get("valu_busy"), "wave_wait_share": pmc.get("wave_wait_share"), "shade": pmc.get("shade"),
               "traffic_source": pmc.get("source"),
               "note": "frac = the busiest memory level's bytes / kernel time / that level's peak (levels: L2 hits vs 34.5 TB/s, L2 misses vs the "
                       "8.6 TB/s random-row rate of the Infinity Cache, fabric bytes vs 8 TB/s HBM).  All three are far from their peaks: the kernel "
-                      "is bound by the rate at which a CU's vector-memory path takes divergent 64-byte record fetches (tools/ubench_fat: ~113 ns per "
-                      "128-B line + ~67 ns per 64-B sector per 64 lanes per CU), `ta_busy` is the address unit's busy share"})
+                      "is bound by chains of dependent record fetches (a wave-step waits for its slowest lane: `wave_wait_share` of the wave cycles "
+                      "sit in s_waitcnt) with the VALU (`valu_busy` = 4 x SQ_INSTS_VALU / SIMD cycles) and the vector-memory address unit (`ta_busy`) "
+                      "as the busiest units; profiles/r3/README.md has the formulas"})
     return r
 
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 5   /* 5: rt_material carries all of material_t + texture options, rt_batch_stats;
+#define RT_ABI_VERSION 5   /* 5: rt_material carries all of material_t + texture options, rt_batch_stats, rt_profile_end_phases, rt_debug_device_allocations;
                               2: rt_render_stats.pixels_traced, rt_render_device_noalloc, cache-file trailer; 3: rt_render_batch_device; 4: rt_frame_rect, rt_assemble_device_on, RT_MAX_BATCH 32 */
 
 enum {
@@ -383,6 +383,10 @@ int rt_bvh_adopt_device(rt_ctx* ctx, const rt_bvh_view* view);
  * ms_traverse = the traversal kernel alone. */
 int rt_profile_begin(rt_ctx* ctx);
 int rt_profile_end(rt_ctx* ctx, float* ms_frame_avg, float* ms_traverse_avg, uint32_t* n_frames);
+/* The same with the traversal time by launch: rt_render_batch_device runs RT_MODE_PRIMARY / SHADOW pipelines as two traversal
+ * launches - the primary rays' walk, then the colour of the pixels that hit something - and ms_traverse_avg / ms_shade_avg are
+ * their two durations (ms_shade_avg = 0 where a pipeline has one traversal launch; rt_profile_end's figure is their sum). */
+int rt_profile_end_phases(rt_ctx* ctx, float* ms_frame_avg, float* ms_traverse_avg, float* ms_shade_avg, uint32_t* n_frames);
 
 /* Frame-coherent scheduling (on by default; no counterpart in the reference).  Every frame leaves one cost class per
  * pixel (how many traversal steps its rays took); the next frame of the same shape traces last frame's long pixels

@@ -447,6 +447,12 @@ class Context:
     def profile_begin(self):
         self._chk(_L.rt_profile_begin(self._h))
 
+    def profile_end_phases(self):
+        """-> (ms_frame_avg, ms_traverse_avg, ms_shade_avg, n): as profile_end, the traversal time by launch (rt_profile_end_phases)."""
+        a, b, c, n = C.c_float(), C.c_float(), C.c_float(), C.c_uint32()
+        self._chk(_L.rt_profile_end_phases(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
+        return a.value, b.value, c.value, n.value
+
     def profile_end(self):
         """-> (ms_frame_avg, ms_traverse_avg, n_frames) over the frames launched since profile_begin."""
         a, b, n = C.c_float(), C.c_float(), C.c_uint32()

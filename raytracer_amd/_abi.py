@@ -31,7 +31,7 @@ SYMBOLS = [
     "rt_set_surface", "rt_get_tri_uv", "rt_set_tri_uv", "rt_set_materials", "rt_set_texture", "rt_tri_uv_device",
     "rt_adopt_tri_uv_device", "rt_tri_uv_export_device", "rt_set_frames_in_flight", "rt_frames_join", "rt_set_coherent_scheduling",
     "rt_render_device_noalloc",
-    "rt_render_batch_device", "rt_frame_rect", "rt_assemble_device_on", "rt_batch_stats", "rt_debug_device_allocations",
+    "rt_render_batch_device", "rt_frame_rect", "rt_assemble_device_on", "rt_batch_stats", "rt_debug_device_allocations", "rt_profile_end_phases",
 ]
 
 
@@ -171,6 +171,7 @@ def load():
         "rt_render_device": (C.c_int, [vp, vp, C.POINTER(RenderOpts), vp, vp, vp, C.POINTER(RenderStats)]),
         "rt_render_device_noalloc": (C.c_int, [vp, vp, C.POINTER(RenderOpts), vp, vp, vp]),
         "rt_render_batch_device": (C.c_int, [vp, C.c_uint32, vp, C.POINTER(RenderOpts), vp, vp, vp]),
+        "rt_profile_end_phases": (C.c_int, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint32)]),
         "rt_batch_stats": (C.c_int, [vp, C.c_uint32, C.POINTER(RenderStats)]),
         "rt_packed_rows": (u32, [u32, i32, i32, i32]),
         "rt_deinterleave_device": (C.c_int, [vp, vp, vp, u32, u32, u32, i32, i32, u32]),

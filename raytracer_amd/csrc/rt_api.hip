@@ -1059,11 +1059,11 @@ int render_frame(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* op
   }
   if (out && p.n_tiles == 0) HIPCHK(hipMemsetAsync(p.stats, 0, sizeof(unsigned long long) * 8, s));
   hipEvent_t* E = nullptr;   // {frame begin, k_render begin, k_render end, frame end}
-  if (ctx->prof_on) { E = &ctx->prof_ev[4 * (size_t)(ctx->prof_n % rt_ctx::PROF_RING)]; ctx->prof_n += (p.n_tiles > 0); }
+  if (ctx->prof_on) { E = &ctx->prof_ev[5 * (size_t)(ctx->prof_n % rt_ctx::PROF_RING)]; ctx->prof_n += (p.n_tiles > 0); }
   else if (out) E = ctx->ev;
   if (p.n_tiles > 0) {
     if (E) HIPCHK(hipEventRecord(E[0], s));
-    rt_launch_render(p, opts->layout, (opts->flags & RT_FLAG_COUNT_WORK) != 0, out != nullptr, ctx->n_cu, s, E ? E[1] : nullptr, E ? E[2] : nullptr);
+    rt_launch_render(p, opts->layout, (opts->flags & RT_FLAG_COUNT_WORK) != 0, out != nullptr, ctx->n_cu, s, E ? E[1] : nullptr, E ? E[2] : nullptr, E ? E[4] : nullptr);
     HIPCHK(hipGetLastError());
     if (E) HIPCHK(hipEventRecord(E[3], s));
   }
@@ -1213,9 +1213,9 @@ int render_batch(rt_ctx* ctx, uint32_t n_frames, const float* uniforms, const rt
   rt_launch_put_frames(recs, n_frames, ctx->r_frames[slot].p, s);     // (the slot's previous batch ran on this same stream: in order)
   bt.frames = ctx->r_frames[slot].p;
   hipEvent_t* E = nullptr;   // {batch begin, k_render begin, k_render end, batch end}: rt_profile_end reports per batch
-  if (ctx->prof_on) { E = &ctx->prof_ev[4 * (size_t)(ctx->prof_n % rt_ctx::PROF_RING)]; ctx->prof_n += 1; }
+  if (ctx->prof_on) { E = &ctx->prof_ev[5 * (size_t)(ctx->prof_n % rt_ctx::PROF_RING)]; ctx->prof_n += 1; }
   if (E) HIPCHK(hipEventRecord(E[0], s));
-  rt_launch_render_batch(p, bt, opts->layout, count_work, ctx->n_cu, s, E ? E[1] : nullptr, E ? E[2] : nullptr);
+  rt_launch_render_batch(p, bt, opts->layout, count_work, ctx->n_cu, s, E ? E[1] : nullptr, E ? E[2] : nullptr, E ? E[4] : nullptr);
   HIPCHK(hipGetLastError());
   if (count_work) { ctx->bstats_slot = slot; ctx->bstats_n = n_frames; }
   if (E) HIPCHK(hipEventRecord(E[3], s));
@@ -1306,14 +1306,14 @@ extern "C" int rt_profile_begin(rt_ctx* ctx) {
   if (!ctx) return RT_ERR_INVALID;
   DeviceGuard g(ctx->device);
   if (ctx->prof_ev.empty()) {
-    ctx->prof_ev.resize(4 * (size_t)rt_ctx::PROF_RING, nullptr);
+    ctx->prof_ev.resize(5 * (size_t)rt_ctx::PROF_RING, nullptr);
     for (auto& e : ctx->prof_ev) HIPCHK(hipEventCreate(&e));
   }
   ctx->prof_on = true; ctx->prof_n = 0;
   return RT_OK;
 }
 
-extern "C" int rt_profile_end(rt_ctx* ctx, float* ms_frame_avg, float* ms_traverse_avg, uint32_t* n_frames) {
+extern "C" int rt_profile_end_phases(rt_ctx* ctx, float* ms_frame_avg, float* ms_traverse_avg, float* ms_shade_avg, uint32_t* n_frames) {
   if (!ctx) return RT_ERR_INVALID;
   if (!ctx->prof_on) return ctx->fail(RT_ERR_INVALID, "rt_profile_end without rt_profile_begin");
   DeviceGuard g(ctx->device);
@@ -1321,17 +1321,27 @@ extern "C" int rt_profile_end(rt_ctx* ctx, float* ms_frame_avg, float* ms_traver
   ctx->prof_on = false;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   const uint32_t n = std::min<uint32_t>(ctx->prof_n, rt_ctx::PROF_RING);   // the ring keeps the last PROF_RING frames
-  double fsum = 0.0, tsum = 0.0;
-  for (uint32_t i = 0; i < n; ++i) {
-    float a = 0.f, b = 0.f;
-    HIPCHK(hipEventElapsedTime(&a, ctx->prof_ev[4 * (size_t)i + 0], ctx->prof_ev[4 * (size_t)i + 3]));
-    HIPCHK(hipEventElapsedTime(&b, ctx->prof_ev[4 * (size_t)i + 1], ctx->prof_ev[4 * (size_t)i + 2]));
-    fsum += a; tsum += b;
+  double fsum = 0.0, tsum = 0.0, ssum = 0.0;
+  for (uint32_t i = 0; i < n; ++i) {   // {pipeline begin, traversal begin, last traversal launch's end, pipeline end, first traversal launch's end}
+    const hipEvent_t* E = &ctx->prof_ev[5 * (size_t)i];
+    float a = 0.f, b = 0.f, c = 0.f;
+    HIPCHK(hipEventElapsedTime(&a, E[0], E[3]));
+    HIPCHK(hipEventElapsedTime(&b, E[1], E[4]));
+    HIPCHK(hipEventElapsedTime(&c, E[4], E[2]));
+    fsum += a; tsum += b; ssum += c;
   }
   if (ms_frame_avg) *ms_frame_avg = n ? (float)(fsum / n) : 0.f;
   if (ms_traverse_avg) *ms_traverse_avg = n ? (float)(tsum / n) : 0.f;
+  if (ms_shade_avg) *ms_shade_avg = n ? (float)(ssum / n) : 0.f;
   if (n_frames) *n_frames = n;
   return RT_OK;
+}
+
+extern "C" int rt_profile_end(rt_ctx* ctx, float* ms_frame_avg, float* ms_traverse_avg, uint32_t* n_frames) {
+  float t = 0.f, sh = 0.f;
+  const int rc = rt_profile_end_phases(ctx, ms_frame_avg, &t, &sh, n_frames);
+  if (rc == RT_OK && ms_traverse_avg) *ms_traverse_avg = t + sh;
+  return rc;
 }
 
 extern "C" int rt_render(rt_ctx* ctx, const float uniforms[44], const rt_render_opts* opts, uint8_t* rgba8, uint32_t* hit_tri,

@@ -181,12 +181,13 @@ uint32_t rt_shard_stride();
 // ev0/ev1 (optional) are recorded immediately before/after the traversal kernel proper
 // want_stats == false skips the k_stats_final reduction (p.stats is then not written)
 // p.tri_uv != NULL selects the textured instantiation
+// ev_mid (optional): recorded behind the FIRST traversal launch (frames that run as traversal + shade launches)
 void rt_launch_render(const RtRenderParams& p, int layout, bool count_work, bool want_stats, int n_cu, hipStream_t s,
-                      hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+                      hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, hipEvent_t ev_mid = nullptr);
 // the same pipeline over bt.n frames (no stats, no PT split, compute.wgsl modes only)
 // count_work: p.stats_partial = [bt.n][resident waves][8] u64 (zeroed here), p.stats = [bt.n][9] u64 totals (8 counters + pixels traced)
 void rt_launch_render_batch(const RtRenderParams& p, const RtBatch& bt, int layout, bool count_work, int n_cu, hipStream_t s,
-                            hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+                            hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, hipEvent_t ev_mid = nullptr);
 void rt_launch_put_frames(const RtFrameRec* host_recs, uint32_t n, RtFrameRec* d_frames, hipStream_t s);
 // BVH-order surface records: record i <- input triangle order[i]
 void rt_launch_gather_uv(const float* texcoords, const uint32_t* tex_idx, const int32_t* material_ids, const uint32_t* order,

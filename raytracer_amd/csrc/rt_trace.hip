@@ -1581,7 +1581,7 @@ void rt_cull_rect(RtRenderParams& p, const float rb[8]) {
 }
 
 void rt_launch_render(const RtRenderParams& p_in, int layout, bool count_work, bool want_stats, int n_cu, hipStream_t s, hipEvent_t ev0,
-                      hipEvent_t ev1) {
+                      hipEvent_t ev1, hipEvent_t ev_mid) {
   RtRenderParams p = p_in;
   const dim3 b(TBLK), gc(rt_cull_blocks(p.n_tiles));
   const bool tex = p.tri_uv != nullptr, split = p.pt_cap != 0;
@@ -1606,6 +1606,7 @@ void rt_launch_render(const RtRenderParams& p_in, int layout, bool count_work, b
   if (ev0) (void)hipEventRecord(ev0, s);
   void* args[2] = {&p, &nb};
   (void)hipLaunchKernel(kernel, g, b, args, lds, s);
+  if (ev_mid) (void)hipEventRecord(ev_mid, s);          // behind the first traversal launch (the only one unless the frame is split)
   uint32_t stat_blocks = split ? 2u * g.x : g.x;
   if (two_phase) {
     const void* shade = render_kernel(layout, count_work, tex, KIND_SHADE, false);
@@ -1637,7 +1638,8 @@ void rt_launch_render(const RtRenderParams& p_in, int layout, bool count_work, b
 // A batch: the frames' cull / scan / compact passes as one grid dimension of three launches, then ONE persistent k_render over all
 // the frames' lists (rt_render_batch_device).  p carries what the frames share (tree, geometry of the image, scratch
 // bases); bt what differs.  No stats, no PT split.
-void rt_launch_render_batch(const RtRenderParams& p_in, const RtBatch& bt, int layout, bool count_work, int n_cu, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+void rt_launch_render_batch(const RtRenderParams& p_in, const RtBatch& bt, int layout, bool count_work, int n_cu, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1,
+                            hipEvent_t ev_mid) {
   RtRenderParams p = p_in;
   RtBatch batch = bt;
   const dim3 b(TBLK), gc(rt_cull_blocks(p.n_tiles), bt.n);
@@ -1666,6 +1668,7 @@ void rt_launch_render_batch(const RtRenderParams& p_in, const RtBatch& bt, int l
   if (ev0) (void)hipEventRecord(ev0, s);
   void* args[2] = {&p, &batch};
   (void)hipLaunchKernel(kernel, dim3(p.render_blocks), b, args, lds, s);
+  if (ev_mid) (void)hipEventRecord(ev_mid, s);
   if (two_phase) {
     void* args2[2] = {&p2, &batch};
     (void)hipLaunchKernel(shade, dim3(p2.render_blocks), b, args2, 0, s);

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Copy what scripts/refresh_profiles.sh measured (gpurun_out/refresh/) into profiles/<round>/ (default r2) and rebuild profiles/traffic.json.
+"""Copy what scripts/refresh_profiles.sh measured (gpurun_out/refresh/) into profiles/<round>/ (default r3) and rebuild
+profiles/traffic.json, the per-frame PMC figures bench.py's `roofline` reads back.
 usage: collect_profiles.py [round-dir-name]"""
 import glob
 import json
@@ -8,7 +9,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-RND = sys.argv[1] if len(sys.argv) > 1 else "r2"
+RND = sys.argv[1] if len(sys.argv) > 1 else "r3"
 src, dst = os.path.join(ROOT, "gpurun_out", "refresh"), os.path.join(ROOT, "profiles", RND)
 os.makedirs(dst, exist_ok=True)
 for f in glob.glob(os.path.join(src, "bench_*.json")):
@@ -19,51 +20,61 @@ for f in glob.glob(os.path.join(src, "bench_*.json")):
     json.loads(line[-1])
     shutil.copy(f, os.path.join(dst, os.path.basename(f)))
 shutil.copy(os.path.join(src, "ks", "kernel_stats.csv"), os.path.join(dst, "kernel_stats.csv"))
-shutil.copy(os.path.join(src, "pmc_summary.txt"), os.path.join(dst, "pmc_summary.txt"))
+for f in ("pmc_summary.txt", "pmc_calib.txt"):
+    if os.path.exists(os.path.join(src, f)):
+        shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 with open(os.path.join(src, "gpu_tests.log")) as f:
     open(os.path.join(dst, "gpu_tests.log"), "w").write("".join(f.readlines()[-3:]))
 allk = json.load(open(os.path.join(src, "traffic_all.json")))
-main = [k for k in allk if k.startswith("k_render<0, false, true, 0, true")]      # WIDE64, no counters, textured, pixel kind, batch
-assert len(main) == 1, list(allk)
-ks_bench = json.loads(open(os.path.join(src, "ks", "bench.json")).read().strip().splitlines()[-1])
-# launches of the batch kernel in one pass of `--steps 20 --warmup 5`: set-up batch (16 frames), warm-up (5), timed (10 + 10)
-FRAMES_PER_LAUNCH = (32 + 5 + 20) / 3.0        # the batch kernel's launches in `bench.py --steps 20 --warmup 5`: set-up 32, warm-up 5, timed 20
+K = 20                                         # bench.py --steps 20: the LAST dispatch of the batch kernels in every pass is the timed pipeline of 20 frames
+trav = [k for k in allk if k.startswith("k_render<0, false, false, 4, true")]      # WIDE64, no counters, KIND_TRAVERSE, batch
+shade = [k for k in allk if k.startswith("k_render<0, false, true, 5, true")]      # WIDE64, no counters, textured, KIND_SHADE, batch
+assert len(trav) == 1 and len(shade) == 1, list(allk)
+
+
+def per_frame(name):
+    d = allk[name]["derived_last"]
+    return {"l2_hit_bytes_per_frame": d["l2_hit_bytes"] / K, "l2_miss_bytes_per_frame": d["l2_miss_bytes"] / K, "fabric_bytes_per_frame": d["fabric_bytes"] / K,
+            "l2_hit_rate": d.get("l2_hit_rate"), "valu_lane_util": d.get("valu_lane_util"), "ta_busy": d.get("ta_busy"), "valu_busy": d.get("valu_busy"),
+            "wave_wait_share": d.get("wave_wait_share"), "l1_miss_latency_cycles": d.get("l1_miss_latency_cycles"),
+            "launch_us_under_rocprofv3": allk[name]["last_duration_us"], "kernel": name}
+
+
 t = {"workload": {"scene": "s1m", "width": 3840, "height": 2160, "mode": "shadow", "layout": "wide64", "spp": 32, "textured": True,
-                  "frames_per_pipeline": 32},
-     "frames_per_launch": FRAMES_PER_LAUNCH,
-     "source": f"profiles/{RND}/pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE and lane passes of `python3 bench.py --no-cpu-baseline "
-               "--no-fif2 --no-legs --steps 20 --warmup 5`, scripts/pmc_passes.sh; per LAUNCH of the batch kernel, a launch holding "
-               f"{FRAMES_PER_LAUNCH} frames on average: set-up 32, warm-up 5, timed 20)",
-     "correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md, HBM/rocprofv3: gfx950 FETCH_SIZE reports half of the "
-                   "bytes read; Infinity-Cache hits are counted, so this is fabric-side traffic, an upper bound on HBM bytes)",
-     "k_render_fetch_size_kb_raw": allk[main[0]]["fetch_size_kb_raw"], "k_render_write_size_kb_raw": allk[main[0]]["write_size_kb_raw"],
-     "k_render_hbm_bytes_per_launch": allk[main[0]]["hbm_bytes_per_launch"],
-     "k_render_valu_lane_util": allk[main[0]].get("valu_lane_util"),
-     "all_kernels": {k: v["hbm_bytes_per_launch"] for k, v in sorted(allk.items()) if "hbm_bytes_per_launch" in v}}
+                  "frames_per_pipeline": 32, "camera_path": "rotY 1 degree per frame"},
+     "source": f"profiles/{RND}/pmc_summary.txt: rocprofv3 --pmc passes of `python3 bench.py --no-cpu-baseline --no-legs --steps 20 --warmup 5` "
+               "(scripts/pmc_passes.sh), the LAST dispatch of each batch kernel in every pass = the timed pipeline of 20 frames, divided by 20",
+     "conversion": "L2 bytes = TCC_HIT_sum / TCC_MISS_sum x 128 B (one request = one 128-byte line: profiles/" + RND + "/pmc_calib.txt, 1 GiB streamed = "
+                   "8.389 M requests); fabric bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (MI355X_MICROARCH.md, HBM / rocprofv3: gfx950 FETCH_SIZE reports "
+                   "half of the bytes read; Infinity-Cache hits are counted in it, so it is an upper bound on HBM bytes)",
+     "k_render": dict(per_frame(trav[0]), shade=per_frame(shade[0])),
+     "all_kernels_fabric_bytes_per_launch": {k: v["derived_mean"]["fabric_bytes"] for k, v in sorted(allk.items()) if "fabric_bytes" in v.get("derived_mean", {})}}
 json.dump(t, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 b = json.loads(open(os.path.join(dst, "bench_n1.json")).read().strip().splitlines()[-1])
-print("bench_n1:", b["value"], b["unit"], b["ms_per_step"], "ms; roofline", b["roofline"]["frac"], "kernel_ms", b["roofline"]["kernel_ms"],
-      "traffic(old file)", b["roofline"]["traffic"], "-> new", t["k_render_hbm_bytes_per_launch"])
+print("bench_n1:", b["value"], b["unit"], b["ms_per_step"], "ms; roofline", b["roofline"].get("bound"), b["roofline"]["frac"], "kernel_ms", b["roofline"]["kernel_ms"])
 
 # build: kernel trace + stage times, and the fabric traffic of the build kernels (same PMC passes: bench.py builds 5 times)
 for f in ("build_kernel_stats.csv", "build.txt"):
-    shutil.copy(os.path.join(src, "build", f), os.path.join(dst, f))
-for f in ("build_nosurface.txt", "build_cfg5.txt", "batch_gain.txt", "batch_gain_moving.txt", "project_scaling_batch16.txt", "project_scaling_per_frame.txt",
-          "rehearsal_n2.json", "rehearsal_n4.json"):
+    if os.path.exists(os.path.join(src, "build", f)):
+        shutil.copy(os.path.join(src, "build", f), os.path.join(dst, f))
+for f in sorted(os.listdir(src)):
+    if f.endswith(".txt") and f not in ("pmc.txt", "ks.txt", "pmc_summary.txt", "pmc_calib.txt", "calib.txt"):
+        shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+for f in ("rehearsal_n2.json", "rehearsal_n4.json"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 build_kernels = [k for k in allk if k.split("<")[0] in ("k_bounds", "k_bounds_final", "k_morton", "k_onesweep", "k_refit_local", "k_refit_mid", "k_refit_spans")]
-per_build = {k: allk[k]["hbm_bytes_per_launch"] * (3 if k.startswith("k_onesweep") else 1) for k in build_kernels}
+per_build = {k: allk[k]["derived_mean"]["fabric_bytes"] for k in build_kernels if "fabric_bytes" in allk[k].get("derived_mean", {})}
 n_tri = 1310720
+ones = [k for k in per_build if k.startswith("k_onesweep")]
+if len(ones) == 2:      # <true> runs once, <false> twice per build
+    a = [k for k in ones if "true" in k][0]; b_ = [k for k in ones if "false" in k][0]
+    x = per_build.pop(a) + 2 * per_build.pop(b_)
+    per_build["k_onesweep (x3)"] = x
+elif len(ones) == 1:
+    per_build["k_onesweep (x3)"] = 3 * per_build.pop(ones[0])
 bt = {"n_tri": n_tri, "algorithmic_bytes": 560 * n_tri, "fabric_bytes_per_build": per_build, "fabric_bytes_total": sum(per_build.values()),
       "ratio": round(sum(per_build.values()) / (560.0 * n_tri), 3),
-      "note": "k_onesweep: 3 launches per build (both template instances averaged by launch count below); surface records (48-byte index "
-              "records, 32-byte tri_uv) are part of these builds but not of the 560 B/triangle figure"}
-ones = [k for k in build_kernels if k.startswith("k_onesweep")]
-if len(ones) == 2:      # <true> runs once, <false> twice per build
-    per_build.pop(ones[0]); per_build.pop(ones[1])
-    a = [k for k in ones if "true" in k][0]; b_ = [k for k in ones if "false" in k][0]
-    per_build["k_onesweep (x3)"] = allk[a]["hbm_bytes_per_launch"] + 2 * allk[b_]["hbm_bytes_per_launch"]
-    bt["fabric_bytes_total"] = sum(per_build.values()); bt["ratio"] = round(bt["fabric_bytes_total"] / (560.0 * n_tri), 3)
+      "note": "surface records (48-byte index records, 32-byte tri_uv) are part of these builds but not of the 560 B/triangle figure"}
 json.dump(bt, open(os.path.join(dst, "build_traffic.json"), "w"), indent=1)
 print("build fabric traffic / algorithmic:", bt["ratio"], per_build)

@@ -5,7 +5,7 @@ set -e
 out="$GRAFT_REPO_ROOT/$1"; shift
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof" -o t -- python3 "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --no-fif2 --no-legs --steps 20 --warmup 5 "$@" > "$out/bench.json" 2> "$out/err.log"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof" -o t -- python3 "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --no-legs --steps 20 --warmup 5 "$@" > "$out/bench.json" 2> "$out/err.log"
 f=$(find "$out/prof" -name '*kernel_stats.csv' | head -1)
 cp "$f" "$out/kernel_stats.csv"
 python3 - "$out/kernel_stats.csv" <<'PY'

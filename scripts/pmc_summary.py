@@ -53,8 +53,14 @@ for k in sorted(vals):
             der["l2_hit_rate"] = round(c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1.0), 4)
         if "SQ_THREAD_CYCLES_VALU" in c and c.get("SQ_ACTIVE_INST_VALU", 0) > 0:
             der["valu_lane_util"] = round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]), 4)
-        if "TA_BUSY_avr" in c and c.get("GRBM_GUI_ACTIVE", 0) > 0:
-            der["ta_busy"] = round(c["TA_BUSY_avr"] / c["GRBM_GUI_ACTIVE"], 4)
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs: cycles of the launch = GRBM_GUI_ACTIVE / 8 (calib_stream: 169 us x 2.4 GHz)
+        cyc = c.get("GRBM_GUI_ACTIVE", 0) / 8.0
+        if "TA_BUSY_avr" in c and cyc > 0:
+            der["ta_busy"] = round(c["TA_BUSY_avr"] / cyc, 4)                     # busy cycles of the average TA instance / launch cycles
+        if "SQ_INSTS_VALU" in c and cyc > 0:
+            der["valu_busy"] = round(4.0 * c["SQ_INSTS_VALU"] / (1024.0 * cyc), 4)  # a wave64 VALU instruction holds its SIMD16 for 4 cycles; 256 CUs x 4 SIMDs
+        if "SQ_WAIT_ANY" in c and c.get("SQ_WAVE_CYCLES", 0) > 0:
+            der["wave_wait_share"] = round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4)
         if "TCP_TCC_READ_REQ_LATENCY_sum" in c and c.get("TCP_TCC_READ_REQ_sum", 0) > 0:
             der["l1_miss_latency_cycles"] = round(c["TCP_TCC_READ_REQ_LATENCY_sum"] / c["TCP_TCC_READ_REQ_sum"], 1)
     print("   => last dispatch:", json.dumps(o["derived_last"]))
