@@ -60,43 +60,93 @@ RT_DEV uint32_t wave_max_u32(uint32_t v) {
 }
 
 // ---------------------------------------------------------------- mesh layout in HBM
-// The loadObj arrays arrive as separate index arrays (vertex, normal, texcoord triples, material ids).  The refit fetches a
-// triangle's indices through the sort order, and three or four 12-byte gathers from separate arrays pull three or four
-// 128-byte lines per triangle where ONE record per triangle pulls 1.3: at upload (rt_set_mesh / rt_set_surface) the index
-// arrays are interleaved into {v0 v1 v2 n0 | n1 n2 t0 t1 | t2 material - -}: 32 bytes per triangle, 48 with a surface.
-__global__ __launch_bounds__(BLK) void k_interleave(const uint32_t* __restrict__ vidx, const uint32_t* __restrict__ nidx,
-                                                    const uint32_t* __restrict__ tex_idx, const int32_t* __restrict__ material_ids,
-                                                    uint32_t n_tri, uint4* __restrict__ tri_rec) {
+// The loadObj arrays arrive indexed: vertex / normal / texcoord triples into three attribute arrays, material ids.  The refit
+// reads a triangle's attributes THROUGH THE SORT ORDER: from the arrays as they come that is nine scattered 8- or 12-byte
+// reads per triangle, each pulling a 64-byte sector (round 2: 884 MB of fabric traffic for 524 MB of algorithmic bytes, 1.8 x,
+// with one 48-byte index record per triangle in between).  So the mesh is de-indexed ONCE, at upload (rt_set_mesh /
+// rt_set_surface), into one 128-byte record per input triangle - the build then reads exactly two sectors per triangle:
+//   {p0.xyz p1.x | p1.yz p2.xy | p2.z n0.xyz | n1.xyz n2.x | n2.yz uv0 | uv1 uv2 | bits(material) - - - | - - - -}
+// (uv / material slots are filled by rt_set_surface).  Copies only: every float keeps its bits.
+constexpr int MESH_REC = 8;       // float4 per record
+__global__ __launch_bounds__(BLK) void k_pack_mesh(const float* __restrict__ pos, const float* __restrict__ nor, const uint32_t* __restrict__ vidx,
+                                                   const uint32_t* __restrict__ nidx, const float* __restrict__ texcoords,
+                                                   const uint32_t* __restrict__ tex_idx, const int32_t* __restrict__ material_ids,
+                                                   uint32_t n_tri, float4* __restrict__ mesh_rec) {
   const uint32_t t = blockIdx.x * BLK + threadIdx.x;
   if (t >= n_tri) return;
-  const uint32_t i0 = vidx[3 * (size_t)t + 0], i1 = vidx[3 * (size_t)t + 1], i2 = vidx[3 * (size_t)t + 2];
-  const uint32_t n0 = nidx[3 * (size_t)t + 0], n1 = nidx[3 * (size_t)t + 1], n2 = nidx[3 * (size_t)t + 2];
-  uint4* rec = tri_rec + (size_t)t * (tex_idx ? 3 : 2);
+  const V3 p0 = load_vtx(pos, vidx[3 * (size_t)t + 0]), p1 = load_vtx(pos, vidx[3 * (size_t)t + 1]), p2 = load_vtx(pos, vidx[3 * (size_t)t + 2]);
+  const V3 n0 = load_vtx(nor, nidx[3 * (size_t)t + 0]), n1 = load_vtx(nor, nidx[3 * (size_t)t + 1]), n2 = load_vtx(nor, nidx[3 * (size_t)t + 2]);
+  float4* rec = mesh_rec + (size_t)t * MESH_REC;
+  float2 a = make_float2(0.0f, 0.0f), b = a, c = a;
+  uint32_t mat = 0xFFFFFFFFu;
   if (tex_idx) {
-    const uint32_t t0 = tex_idx[3 * (size_t)t + 0], t1 = tex_idx[3 * (size_t)t + 1], t2 = tex_idx[3 * (size_t)t + 2];
-    rec[0] = make_uint4(i0, i1, i2, n0); rec[1] = make_uint4(n1, n2, t0, t1);
-    rec[2] = make_uint4(t2, material_ids ? (uint32_t)material_ids[t] : 0xFFFFFFFFu, 0u, 0u);
-  } else { rec[0] = make_uint4(i0, i1, i2, n0); rec[1] = make_uint4(n1, n2, 0u, 0u); }
+    const float2* tc = reinterpret_cast<const float2*>(texcoords);
+    a = tc[tex_idx[3 * (size_t)t + 0]]; b = tc[tex_idx[3 * (size_t)t + 1]]; c = tc[tex_idx[3 * (size_t)t + 2]];
+    if (material_ids) mat = (uint32_t)material_ids[t];
+  }
+  rec[0] = make_float4(p0.x, p0.y, p0.z, p1.x);
+  rec[1] = make_float4(p1.y, p1.z, p2.x, p2.y);
+  rec[2] = make_float4(p2.z, n0.x, n0.y, n0.z);
+  rec[3] = make_float4(n1.x, n1.y, n1.z, n2.x);
+  rec[4] = make_float4(n2.y, n2.z, a.x, a.y);
+  rec[5] = make_float4(b.x, b.y, c.x, c.y);
+  rec[6] = make_float4(__uint_as_float(mat), 0.0f, 0.0f, 0.0f);
 }
 
 // ---------------------------------------------------------------- centroid bounds
-// Two stages, no atomics: every block leaves its six ordered-uint partials in its own slot (2048 blocks x 6 same-address
-// atomicMin/Max serialised at ~26 ns each: 53 of the kernel's 62 us at 1.3 M triangles), one block folds the slots.
+// No same-address atomics: every block leaves its six ordered-uint partials in its own slot (2048 blocks x 6 same-address
+// atomicMin/Max serialised at ~26 ns each: 53 of the kernel's 62 us at 1.3 M triangles); every block of k_morton folds the
+// slots for itself (30 KB of L2 hits; as a launch of its own the fold cost 4 us + a launch gap.  A "last block folds"
+// ticket inside k_bounds needs an agent-scope release fence per block, and on this chip that is a write-back of the XCD's L2:
+// 1280 of them took 0.22 ms).
 // Also keeps every centroid (12 B/triangle, coalesced) so that k_morton streams them instead of repeating the
 // three-vertex gather through the index buffer (48 B/triangle of scattered reads).
+// The vertex gather is laid out per INDEX SLOT, not per triangle: lane l of a wave takes slots l, 64 + l, 128 + l of the wave's
+// 64 triangles (192 slots), so with the usual nearly-sequential index buffers one load instruction touches 6 lines instead
+// of 64 - the texture path handles ~4 cycles per line touched, and with one lane per triangle (3 vertices = 3 or 12 scattered
+// 12-byte loads per lane, every lane on its own lines) that rate, not HBM, set the kernel's time: 30 us at 1.3 M triangles,
+// 4.4 ms at 99.6 M.  The wave turns the slots into triangles through its own 2.3 KB of LDS.
+constexpr int BOUNDS_MAX_BLOCKS = 2048;
 __global__ __launch_bounds__(BLK) void k_bounds(const float* __restrict__ pos, const uint32_t* __restrict__ vidx,
-                                                uint32_t n_tri, uint32_t* __restrict__ part /* [6][gridDim.x] */,
-                                                float* __restrict__ centroids /* [3T] */) {
+                                                uint32_t n_tri, uint32_t* part /* [6][gridDim.x] */,
+                                                float* __restrict__ centroids /* [3T] */,
+                                                uint32_t* __restrict__ hist, uint32_t* __restrict__ tile_counter) {
+  if (blockIdx.x == 0) {
+    // the sort's global digit histograms and tile tickets start at zero (saves three memset launches)
+    for (int i = threadIdx.x; i < SORT_PASSES * RADIX; i += BLK) hist[i] = 0u;
+    if (threadIdx.x < 4) tile_counter[threadIdx.x] = 0u;
+    for (int i = threadIdx.x; i < 64 * 32; i += BLK) tile_counter[32 + i] = 0u;      // the refit's lists of block-crossing nodes (CROSS_SHARDS x CROSS_STRIDE)
+  }
+  __shared__ float s_vtx[BLK / 64][192 * 3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* win = s_vtx[wave];
   uint32_t mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u};
-  for (uint32_t t = blockIdx.x * BLK + threadIdx.x; t < n_tri; t += gridDim.x * BLK) {
-    V3 c = tri_centroid(pos, vidx, t);
-    centroids[3 * (size_t)t + 0] = c.x; centroids[3 * (size_t)t + 1] = c.y; centroids[3 * (size_t)t + 2] = c.z;
-    uint32_t e[3] = {f2ord(c.x), f2ord(c.y), f2ord(c.z)};
+  const size_t n_slots = 3 * (size_t)n_tri;
+  for (size_t t0 = ((size_t)blockIdx.x * (BLK / 64) + wave) * 64; t0 < n_tri; t0 += (size_t)gridDim.x * BLK) {   // the wave's 64 triangles
+    uint32_t ix[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { mn[k] = min(mn[k], e[k]); mx[k] = max(mx[k], e[k]); }
+    for (int r = 0; r < 3; ++r) { const size_t sl = 3 * t0 + 64 * r + lane; ix[r] = (sl < n_slots) ? vidx[sl] : 0u; }
+    V3 v[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) v[r] = load_vtx(pos, ix[r]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { float* w = win + 3 * (64 * r + lane); w[0] = v[r].x; w[1] = v[r].y; w[2] = v[r].z; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const size_t t = t0 + lane;
+    if (t < n_tri) {
+      const float* q = win + 9 * lane;
+      const V3 c = ((v3(q[0], q[1], q[2]) + v3(q[3], q[4], q[5])) + v3(q[6], q[7], q[8])) / 3.0f;   // web/morton_compute.wgsl:52, as tri_centroid
+      centroids[3 * t + 0] = c.x; centroids[3 * t + 1] = c.y; centroids[3 * t + 2] = c.z;
+      const uint32_t e[3] = {f2ord(c.x), f2ord(c.y), f2ord(c.z)};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { mn[k] = min(mn[k], e[k]); mx[k] = max(mx[k], e[k]); }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                     // the window is rewritten by the next step
   }
   __shared__ uint32_t s[6][BLK / 64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     uint32_t a = wave_min_u32(mn[k]), b = wave_max_u32(mx[k]);
@@ -107,38 +157,35 @@ __global__ __launch_bounds__(BLK) void k_bounds(const float* __restrict__ pos, c
     const int k = threadIdx.x;
     uint32_t v = s[k][0];
     for (int w = 1; w < BLK / 64; ++w) v = (k < 3) ? min(v, s[k][w]) : max(v, s[k][w]);
-    part[(size_t)k * gridDim.x + blockIdx.x] = v;        // component-major: k_bounds_final reads them coalesced
-  }
-}
+    part[(size_t)k * gridDim.x + blockIdx.x] = v;        // component-major: the fold reads them coalesced
+  }}
 
-// fold the block partials (6 waves, one per component), then the `Bounds` uniform of morton_compute.wgsl:3-6:
-// invExtent = 1/(max-min), 0 where the extent is 0
-__global__ __launch_bounds__(384) void k_bounds_final(const uint32_t* __restrict__ part, uint32_t n_blocks, float* bounds_f,
-                                                      uint32_t* __restrict__ hist, uint32_t* __restrict__ tile_counter) {
-  __shared__ uint32_t s[6];
-  // the sort's global digit histograms and tile tickets start at zero (saves three memset launches)
-  for (int i = threadIdx.x; i < SORT_PASSES * RADIX; i += 384) hist[i] = 0u;
-  if (threadIdx.x < 4) tile_counter[threadIdx.x] = 0u;
-  for (int i = threadIdx.x; i < 64 * 32; i += 384) tile_counter[32 + i] = 0u;      // the refit's lists of block-crossing nodes (CROSS_SHARDS x CROSS_STRIDE)
-  const int lane = threadIdx.x & 63, k = threadIdx.x >> 6;
-  uint32_t v = (k < 3) ? 0xFFFFFFFFu : 0u;
-  {   // wave k folds component k: all loads of a wave issued before the first is used (<= 2048 partials: 32 per lane)
-    uint32_t x[32];
+// fold of k_bounds' block partials by one block (wave w: components w and w + 4), then the `Bounds` uniform of
+// morton_compute.wgsl:3-6: invExtent = 1/(max-min), 0 where the extent is 0.  s6: six words of LDS; all threads of the block call.
+RT_DEV void fold_bounds(const uint32_t* __restrict__ part, uint32_t n_blocks, uint32_t* s6, V3& bmin, V3& inv) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = wave; k < 6; k += BLK / 64) {
+    uint32_t v = (k < 3) ? 0xFFFFFFFFu : 0u;
+    uint32_t x[BOUNDS_MAX_BLOCKS / 64];                  // all loads of a wave issued before the first is used
 #pragma unroll
-    for (int it = 0; it < 32; ++it) { const uint32_t b = (uint32_t)lane + 64u * it; x[it] = (b < n_blocks) ? part[(size_t)k * n_blocks + b] : v; }
+    for (int it = 0; it < BOUNDS_MAX_BLOCKS / 64; ++it) {
+      const uint32_t bi = (uint32_t)lane + 64u * it;
+      x[it] = (bi < n_blocks) ? part[(size_t)k * n_blocks + bi] : v;
+    }
 #pragma unroll
-    for (int it = 0; it < 32; ++it) v = (k < 3) ? min(v, x[it]) : max(v, x[it]);
+    for (int it = 0; it < BOUNDS_MAX_BLOCKS / 64; ++it) v = (k < 3) ? min(v, x[it]) : max(v, x[it]);
+    v = (k < 3) ? wave_min_u32(v) : wave_max_u32(v);
+    if (lane == 0) s6[k] = v;
   }
-  v = (k < 3) ? wave_min_u32(v) : wave_max_u32(v);
-  if (lane == 0) s[k] = v;
   __syncthreads();
-  if (threadIdx.x < 3) {
-    const int c = threadIdx.x;
-    float lo = ord2f(s[c]), hi = ord2f(s[3 + c]);
-    float ext = hi - lo;
-    bounds_f[c] = lo;
-    bounds_f[4 + c] = (ext > 0.0f) ? (1.0f / ext) : 0.0f;
-  } else if (threadIdx.x == 3) { bounds_f[3] = 0.0f; bounds_f[7] = 0.0f; }
+  float lo[3], iv[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    lo[c] = ord2f(s6[c]);
+    const float ext = ord2f(s6[3 + c]) - lo[c];
+    iv[c] = (ext > 0.0f) ? (1.0f / ext) : 0.0f;
+  }
+  bmin = v3(lo[0], lo[1], lo[2]); inv = v3(iv[0], iv[1], iv[2]);
 }
 
 // ---------------------------------------------------------------- Morton codes
@@ -146,15 +193,20 @@ __global__ __launch_bounds__(384) void k_bounds_final(const uint32_t* __restrict
 // LDS histogram per block and digit position, flushed with one global atomic per non-empty bin.  Few, fat blocks: the flush
 // costs one same-address atomic per block and bin.
 __global__ __launch_bounds__(BLK) void k_morton(const float* __restrict__ centroids,
-                                                uint32_t n_tri, const float* __restrict__ bounds_f,
+                                                uint32_t n_tri, const uint32_t* __restrict__ bounds_part, uint32_t n_bounds_blocks, float* __restrict__ bounds_f,
                                                 uint32_t* __restrict__ codes, uint32_t* __restrict__ hist,
                                                 uint32_t* __restrict__ tile_status, size_t n_status) {
   __shared__ uint32_t h[SORT_PASSES][RADIX];
   for (int i = threadIdx.x; i < SORT_PASSES * RADIX; i += BLK) (&h[0][0])[i] = 0u;
   // the look-back words of the sort passes start at zero (their own memset launch otherwise)
   for (size_t i = (size_t)blockIdx.x * BLK + threadIdx.x; i < n_status; i += (size_t)gridDim.x * BLK) tile_status[i] = 0u;
-  __syncthreads();
-  const V3 bmin = v3(bounds_f[0], bounds_f[1], bounds_f[2]), inv = v3(bounds_f[4], bounds_f[5], bounds_f[6]);
+  __shared__ uint32_t s6[6];
+  V3 bmin, inv;
+  fold_bounds(bounds_part, n_bounds_blocks, s6, bmin, inv);          // (its barrier also covers the zeroed histograms)
+  if (blockIdx.x == 0 && threadIdx.x == 0) {                        // the uniform itself, for rt_get_bounds
+    bounds_f[0] = bmin.x; bounds_f[1] = bmin.y; bounds_f[2] = bmin.z; bounds_f[3] = 0.0f;
+    bounds_f[4] = inv.x; bounds_f[5] = inv.y; bounds_f[6] = inv.z; bounds_f[7] = 0.0f;
+  }
   // four triangles per step, their centroids loaded before the first is used (a thread walks ~16 triangles: one at a time
   // the loop is a chain of exposed load latencies)
   constexpr int MU = 4;
@@ -650,17 +702,40 @@ RT_DEV void store_wide(float4* wide, int par, int c0, int c1, int first_leaf, V3
   wide[4 * (size_t)par + 3] = make_float4(b_mx.x, b_mx.y, b_mx.z, 0.0f);
 }
 
-__global__ __launch_bounds__(BLK) void k_refit_local(const float* __restrict__ pos, const float* __restrict__ nor,
-                                                     const uint4* __restrict__ tri_rec,
+// N float4 per lane, lane l's at dst[l * N .. l * N + N): written as they stand, one store instruction of the wave covers 64
+// pieces of 16 bytes spread over N KB, and the chip takes such stores at 4.4 TB/s; turned through the wave's LDS window so that
+// every store instruction writes ONE contiguous 1 KB run it takes 5.6 TB/s (tools/ubench_stream, variants 0 / 4).
+// `ok`: which lanes' records are to be written.  The window is the wave's own: LDS operations of one wave are in order, the
+// fences only keep the compiler from moving them.
+template <int N>
+RT_DEV void wave_store_run(float4* win, float4* dst, const float4 (&v)[N], unsigned long long ok, int lane) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) win[lane * N + i] = v[i];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int e = 64 * i + lane;
+    if ((ok >> (e / N)) & 1ull) dst[e] = win[e];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();                     // the window is rewritten by the next run
+}
+
+__global__ __launch_bounds__(BLK) void k_refit_local(const float4* __restrict__ mesh_rec,
                                                      const uint32_t* __restrict__ order, const uint32_t* __restrict__ keys, uint32_t n_tri,
                                                      int32_t* __restrict__ span,
                                                      float* __restrict__ nodes, float* __restrict__ tri_pos,
                                                      float* __restrict__ tri_nor, float4* __restrict__ wide, float4* __restrict__ tri_pre,
-                                                     const float* __restrict__ texcoords, float4* __restrict__ tri_uv,
+                                                     float4* __restrict__ tri_uv /* NULL: no surface records */,
                                                      float4* __restrict__ mini_box, float4* __restrict__ chunk_box,
                                                      uint32_t* __restrict__ block_key, uint32_t* cross_cnt, uint32_t* __restrict__ cross_list,
                                                      uint32_t cross_cap, bool v2) {
-  __shared__ float s_box[2 * BLK][6];      // [0, BLK): this block's leaves, [BLK, 2 BLK): internal nodes with index in the block's range
+  // [0, BLK): this block's leaves, [BLK, 2 BLK): internal nodes with index in the block's range.  Before and after the climb
+  // the same 12 KB are the waves' store windows (wave_store_run): 3 KB each
+  __shared__ float4 s_win[2 * BLK * 6 / 4];
+  float (*s_box)[6] = reinterpret_cast<float (*)[6]>(s_win);
   __shared__ uint32_t s_visit[BLK];        // arrival counters of the block-local internal nodes
   __shared__ int s_child[BLK][2];          // children of the block-local internal nodes
   __shared__ int s_par[2 * BLK];           // parent of every leaf / internal slot if that parent is block-local, else -1
@@ -727,39 +802,45 @@ __global__ __launch_bounds__(BLK) void k_refit_local(const float* __restrict__ p
     s_cross[BLK / 64] = run ? atomicAdd(cross_cnt + (blockIdx.x % CROSS_SHARDS) * CROSS_STRIDE, run) : 0u;
   }
   V3 mn = v3(BOX_INF, BOX_INF, BOX_INF), mx = v3(-BOX_INF, -BOX_INF, -BOX_INF);
-  if (valid) {
-    V3 p[3];
-    float4* tp = reinterpret_cast<float4*>(tri_pos) + (size_t)j * 3;
-    float4* tn = reinterpret_cast<float4*>(tri_nor) + (size_t)j * 3;
-    const uint4* rec = tri_rec + (size_t)ti * (texcoords ? 3 : 2);     // k_bounds: {v0 v1 v2 n0 | n1 n2 t0 t1 | t2 material - -}
-    const uint4 ra = rec[0], rb = rec[1];
-    const uint32_t vi[3] = {ra.x, ra.y, ra.z}, ni[3] = {ra.w, rb.x, rb.y};
-#pragma unroll
-    for (int v = 0; v < 3; ++v) {                     // web/script.js:530-545
-      p[v] = load_vtx(pos, vi[v]);
-      V3 nn = load_vtx(nor, ni[v]);
-      tp[v] = make_float4(p[v].x, p[v].y, p[v].z, 0.0f);
-      tn[v] = make_float4(nn.x, nn.y, nn.z, 0.0f);
+  {
+    const int lane = threadIdx.x & 63;
+    float4* win = s_win + (threadIdx.x >> 6) * (3 * 64);               // this wave's 3 KB
+    const size_t wj = j - (uint32_t)lane;                             // the wave's first triangle: its runs in the sorted arrays start there
+    const unsigned long long ok = __ballot(valid);
+    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 r0 = zero4, r1 = zero4, r2 = zero4, r3 = zero4, r4 = zero4, r5 = zero4, r6 = zero4;
+    if (valid) {
+      const float4* rec = mesh_rec + (size_t)ti * MESH_REC;           // k_pack_mesh: the input triangle's attributes, two 64-byte sectors
+      r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3]; r4 = rec[4];
+      if (tri_uv) { r5 = rec[5]; r6 = rec[6]; }
+    }
+    const V3 p[3] = {v3(r0.x, r0.y, r0.z), v3(r0.w, r1.x, r1.y), v3(r1.z, r1.w, r2.x)};
+    const V3 nn[3] = {v3(r2.y, r2.z, r2.w), v3(r3.x, r3.y, r3.z), v3(r3.w, r4.x, r4.y)};
+    {                                                  // web/script.js:530-545
+      const float4 tp[3] = {make_float4(p[0].x, p[0].y, p[0].z, 0.0f), make_float4(p[1].x, p[1].y, p[1].z, 0.0f), make_float4(p[2].x, p[2].y, p[2].z, 0.0f)};
+      wave_store_run<3>(win, reinterpret_cast<float4*>(tri_pos) + 3 * wj, tp, ok, lane);
+      const float4 tn[3] = {make_float4(nn[0].x, nn[0].y, nn[0].z, 0.0f), make_float4(nn[1].x, nn[1].y, nn[1].z, 0.0f), make_float4(nn[2].x, nn[2].y, nn[2].z, 0.0f)};
+      wave_store_run<3>(win, reinterpret_cast<float4*>(tri_nor) + 3 * wj, tn, ok, lane);
     }
     {                                                  // traversal layout of the triangle, the statements of k_pack_tris
       const V3 e1 = p[1] - p[0], e2 = p[2] - p[0];
       const V3 ng = cross3(e1, e2);
-      tri_pre[3 * (size_t)j + 0] = make_float4(p[0].x, p[0].y, p[0].z, ng.x);
-      tri_pre[3 * (size_t)j + 1] = make_float4(e1.x, e1.y, e1.z, ng.y);
-      tri_pre[3 * (size_t)j + 2] = make_float4(e2.x, e2.y, e2.z, ng.z);
+      const float4 pre[3] = {make_float4(p[0].x, p[0].y, p[0].z, ng.x), make_float4(e1.x, e1.y, e1.z, ng.y), make_float4(e2.x, e2.y, e2.z, ng.z)};
+      wave_store_run<3>(win, tri_pre + 3 * wj, pre, ok, lane);
     }
-    if (texcoords) {                                   // surface record (rtcore.h "material / texture shading"), as k_gather_uv
-      const uint4 rc = rec[2];
-      const float2* tc = reinterpret_cast<const float2*>(texcoords);
-      const float2 a = tc[rb.z], b = tc[rb.w], c = tc[rc.x];
-      tri_uv[2 * (size_t)j + 0] = make_float4(a.x, a.y, b.x, b.y);
-      tri_uv[2 * (size_t)j + 1] = make_float4(c.x, c.y, __uint_as_float(rc.y), 0.0f);
+    if (tri_uv) {                                      // surface record (rtcore.h "material / texture shading"), as k_gather_uv
+      const float4 uv[2] = {make_float4(r4.z, r4.w, r5.x, r5.y), make_float4(r5.z, r5.w, r6.x, 0.0f)};
+      wave_store_run<2>(win, tri_uv + 2 * wj, uv, ok, lane);
     }
-    // true triangle bounds (web/script.js:309-316)
-    mn = v3(fminf(fminf(p[0].x, p[1].x), p[2].x), fminf(fminf(p[0].y, p[1].y), p[2].y), fminf(fminf(p[0].z, p[1].z), p[2].z));
-    mx = v3(fmaxf(fmaxf(p[0].x, p[1].x), p[2].x), fmaxf(fmaxf(p[0].y, p[1].y), p[2].y), fmaxf(fmaxf(p[0].z, p[1].z), p[2].z));
-    store_node(nodes, first_leaf + (int)j, mn, enc_index(v2, j), mx, enc_leaf_b(v2, 1u));   // A = tri_start, B = -count (script.js:348,554,558)
+    if (valid) {                                       // true triangle bounds (web/script.js:309-316)
+      mn = v3(fminf(fminf(p[0].x, p[1].x), p[2].x), fminf(fminf(p[0].y, p[1].y), p[2].y), fminf(fminf(p[0].z, p[1].z), p[2].z));
+      mx = v3(fmaxf(fmaxf(p[0].x, p[1].x), p[2].x), fmaxf(fmaxf(p[0].y, p[1].y), p[2].y), fmaxf(fmaxf(p[0].z, p[1].z), p[2].z));
+    }
+    // leaf record: A = tri_start, B = -count (script.js:348,554,558), the words of store_node
+    const float4 leaf[2] = {make_float4(mn.x, mn.y, mn.z, enc_index(v2, j)), make_float4(mx.x, mx.y, mx.z, enc_leaf_b(v2, 1u))};
+    wave_store_run<2>(win, reinterpret_cast<float4*>(nodes) + 2 * ((size_t)first_leaf + wj), leaf, ok, lane);
   }
+  __syncthreads();                                     // the windows become the climb's boxes
   {   // boxes of aligned groups of 16 and 64 leaves (the valid ones), from one xor butterfly: the ragged ends of the ranges in k_refit_spans
     const int lane = threadIdx.x & 63;
     V3 a = mn, b = mx;
@@ -803,13 +884,45 @@ __global__ __launch_bounds__(BLK) void k_refit_local(const float* __restrict__ p
     sb[0] = mn.x; sb[1] = mn.y; sb[2] = mn.z; sb[3] = mx.x; sb[4] = mx.y; sb[5] = mx.z;
   }
   __syncthreads();
-  if (j + 1 < n_tri && s_visit[threadIdx.x] == 2u) {   // internal node j was finished here: both children are in LDS
-    const int c0 = s_child[threadIdx.x][0], c1 = s_child[threadIdx.x][1];
-    const float* a = s_box[(c0 >= first_leaf) ? ((c0 - first_leaf) & (BLK - 1)) : (BLK + (c0 & (BLK - 1)))];
-    const float* b = s_box[(c1 >= first_leaf) ? ((c1 - first_leaf) & (BLK - 1)) : (BLK + (c1 & (BLK - 1)))];
-    const float* m = s_box[BLK + threadIdx.x];
-    store_wide(wide, (int)j, c0, c1, first_leaf, v3(a[0], a[1], a[2]), v3(a[3], a[4], a[5]), v3(b[0], b[1], b[2]), v3(b[3], b[4], b[5]));
-    store_node(nodes, (int)j, v3(m[0], m[1], m[2]), enc_index(v2, (uint32_t)c0), v3(m[3], m[4], m[5]), enc_index(v2, (uint32_t)c1));   // v1: indices as f32 values (F11)
+  {
+    const bool done = j + 1 < n_tri && s_visit[threadIdx.x] == 2u;   // internal node j was finished here: both children are in LDS
+    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 w[4] = {zero4, zero4, zero4, zero4}, nd[2] = {zero4, zero4};
+    if (done) {
+      const int c0 = s_child[threadIdx.x][0], c1 = s_child[threadIdx.x][1];
+      const float* a = s_box[(c0 >= first_leaf) ? ((c0 - first_leaf) & (BLK - 1)) : (BLK + (c0 & (BLK - 1)))];
+      const float* b = s_box[(c1 >= first_leaf) ? ((c1 - first_leaf) & (BLK - 1)) : (BLK + (c1 & (BLK - 1)))];
+      const float* m = s_box[BLK + threadIdx.x];
+      // the words of store_wide and store_node
+      const uint32_t q0 = (c0 >= first_leaf) ? (0x80000000u | (uint32_t)(c0 - first_leaf)) : (uint32_t)c0;
+      const uint32_t q1 = (c1 >= first_leaf) ? (0x80000000u | (uint32_t)(c1 - first_leaf)) : (uint32_t)c1;
+      w[0] = make_float4(a[0], a[1], a[2], __uint_as_float(q0)); w[1] = make_float4(a[3], a[4], a[5], __uint_as_float(q1));
+      w[2] = make_float4(b[0], b[1], b[2], 0.0f); w[3] = make_float4(b[3], b[4], b[5], 0.0f);
+      nd[0] = make_float4(m[0], m[1], m[2], enc_index(v2, (uint32_t)c0)); nd[1] = make_float4(m[3], m[4], m[5], enc_index(v2, (uint32_t)c1));   // v1: indices as f32 values (F11)
+    }
+    __syncthreads();                                   // every box has been read: the 12 KB are store windows again
+    const int lane = threadIdx.x & 63;
+    float4* win = s_win + (threadIdx.x >> 6) * (3 * 64);
+    const size_t wj = j - (uint32_t)lane;
+    const unsigned long long ok = __ballot(done);      // the other ~4 % are written by k_refit_spans
+    wave_store_run<2>(win, reinterpret_cast<float4*>(nodes) + 2 * wj, nd, ok, lane);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {             // 64-byte records: 32 lanes' worth (2 KB) fit the window
+      if ((lane >> 5) == half) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) win[(lane & 31) * 4 + i] = w[i];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int e = 64 * i + lane;
+        if ((ok >> (32 * half + e / 4)) & 1ull) wide[4 * (wj + 32 * half) + e] = win[e];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
   }
   if (is_crossing) {
     const int lane = threadIdx.x & 63;
@@ -1041,27 +1154,28 @@ static size_t sort_pass_status_bytes(uint32_t tiles) { return (size_t)sort_group
 size_t rt_sort_status_words(uint32_t n) { return (size_t)SORT_PASSES * sort_pass_status_bytes(rt_sort_tile_count(n)) / 4; }
 uint32_t rt_sort_hist_words() { return (uint32_t)(SORT_PASSES * RADIX); }
 
-uint32_t rt_bounds_words() { return 6u * 2048u; }   // grid_for's block cap x 6 partials
+uint32_t rt_bounds_words() { return 6u * BOUNDS_MAX_BLOCKS; }   // the block cap x 6 partials
 void rt_launch_bounds(const RtBuildBuffers& b, hipStream_t s) {
-  const int g = grid_for(b.n_tri, BLK);
-  hipLaunchKernelGGL(k_bounds, dim3(g), dim3(BLK), 0, s, b.pos, b.vidx, b.n_tri, b.bounds_enc, b.centroids);
-  hipLaunchKernelGGL(k_bounds_final, dim3(1), dim3(384), 0, s, b.bounds_enc, (uint32_t)g, b.bounds_f, b.hist, b.tile_counter);
+  const int g = grid_for(b.n_tri, BLK, BOUNDS_MAX_BLOCKS);           // = bounds_grid(n_tri): k_morton folds that many partials
+  hipLaunchKernelGGL(k_bounds, dim3(g), dim3(BLK), 0, s, b.pos, b.vidx, b.n_tri, b.bounds_enc, b.centroids, b.hist, b.tile_counter);
 }
+static int bounds_grid(uint32_t n_tri) { return grid_for(n_tri, BLK, BOUNDS_MAX_BLOCKS); }
 
-void rt_launch_interleave(const uint32_t* vidx, const uint32_t* nidx, const uint32_t* tex_idx, const int32_t* material_ids, uint32_t n_tri,
-                          uint4* tri_rec, hipStream_t s) {
-  hipLaunchKernelGGL(k_interleave, dim3((n_tri + BLK - 1) / BLK), dim3(BLK), 0, s, vidx, nidx, tex_idx, material_ids, n_tri, tri_rec);
+size_t rt_mesh_rec_float4s(uint32_t n_tri) { return (size_t)n_tri * MESH_REC; }
+void rt_launch_pack_mesh(const float* pos, const float* nor, const uint32_t* vidx, const uint32_t* nidx, const float* texcoords,
+                         const uint32_t* tex_idx, const int32_t* material_ids, uint32_t n_tri, float4* mesh_rec, hipStream_t s) {
+  hipLaunchKernelGGL(k_pack_mesh, dim3((n_tri + BLK - 1) / BLK), dim3(BLK), 0, s, pos, nor, vidx, nidx, texcoords, tex_idx, material_ids, n_tri, mesh_rec);
 }
 
 void rt_launch_morton(const RtBuildBuffers& b, hipStream_t s) {
   // few, fat blocks: every block flushes its LDS digit histograms with one global atomic per non-empty bin
-  hipLaunchKernelGGL(k_morton, dim3(grid_for(b.n_tri, BLK * 16, 512)), dim3(BLK), 0, s, b.centroids, b.n_tri, b.bounds_f, b.codes,
+  hipLaunchKernelGGL(k_morton, dim3(grid_for(b.n_tri, BLK * 16, 512)), dim3(BLK), 0, s, b.centroids, b.n_tri, b.bounds_enc, (uint32_t)bounds_grid(b.n_tri), b.bounds_f, b.codes,
                      b.hist, b.tile_status, rt_sort_status_words(b.n_tri));
 }
 
 void rt_launch_sort(const RtBuildBuffers& b, hipStream_t s) {
   const uint32_t n = b.n_tri, tiles = rt_sort_tile_count(n);
-  // hist / tile_counter were zeroed by k_bounds_final, tile_status by k_morton, which also filled hist
+  // hist / tile_counter were zeroed by k_bounds, tile_status by k_morton, which also filled hist
   // codes -> a -> b -> a: the sorted keys / order end up in keys_a / vals_a
   const uint32_t* ki = b.codes; const uint32_t* vi = nullptr;
   uint32_t *ko = b.keys_a, *vo = b.vals_a;
@@ -1108,8 +1222,8 @@ RefitTables refit_tables(const RtBuildBuffers& b) {
 void rt_launch_refit_local(const RtBuildBuffers& b, float* nodes, float* tri_pos, float* tri_nor, float4* wide, float4* tri_pre, bool v2,
                            hipStream_t s) {
   const RefitTables t = refit_tables(b);
-  hipLaunchKernelGGL(k_refit_local, dim3(t.nb), dim3(BLK), 0, s, b.pos, b.nor, b.tri_rec, b.vals_a, b.keys_a, b.n_tri, b.span,
-                     nodes, tri_pos, tri_nor, wide, tri_pre, b.texcoords, b.tri_uv, t.mini_box, t.chunk_box,
+  hipLaunchKernelGGL(k_refit_local, dim3(t.nb), dim3(BLK), 0, s, b.mesh_rec, b.vals_a, b.keys_a, b.n_tri, b.span,
+                     nodes, tri_pos, tri_nor, wide, tri_pre, b.texcoords ? b.tri_uv : nullptr, t.mini_box, t.chunk_box,
                      t.block_key, b.tile_counter + 32, b.cross_list, rt_cross_capacity(b.n_tri), v2);
 }
 
