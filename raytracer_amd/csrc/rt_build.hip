@@ -748,8 +748,17 @@ __global__ __launch_bounds__(BLK) void k_refit_local(const float4* __restrict__ 
   for (int q = threadIdx.x; q < BLK + 2; q += BLK) { const int p = S - 1 + q; if (p >= 0 && p < n) s_key[q] = keys[p]; }
   const uint32_t j = blockIdx.x * BLK + threadIdx.x;
   const bool valid = j < n_tri;
-  const uint32_t ti = valid ? order[j] : 0u;           // issued here, used after the tree search below
+  const uint32_t ti = valid ? order[j] : 0u;
   __syncthreads();
+  // the triangle's record (k_pack_mesh: its attributes, two 64-byte sectors) is requested here and used after the tree
+  // search below, which lives in LDS: the search hides the fetch
+  const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  float4 r0 = zero4, r1 = zero4, r2 = zero4, r3 = zero4, r4 = zero4, r5 = zero4, r6 = zero4;
+  if (valid) {
+    const float4* rec = mesh_rec + (size_t)ti * MESH_REC;
+    r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3]; r4 = rec[4];
+    if (tri_uv) { r5 = rec[5]; r6 = rec[6]; }
+  }
   if (threadIdx.x == 0) block_key[blockIdx.x] = s_key[1];   // key of position S: the coarse probes of k_refit_mid
   // Karras 2012 on the keys in LDS, for internal node i = j.  A probe outside [S, E] is only ever compared with dmin, and a
   // key farther away shares at most as long a prefix as the halo key of that side: if that halo key is still inside the
@@ -807,13 +816,6 @@ __global__ __launch_bounds__(BLK) void k_refit_local(const float4* __restrict__ 
     float4* win = s_win + (threadIdx.x >> 6) * (3 * 64);               // this wave's 3 KB
     const size_t wj = j - (uint32_t)lane;                             // the wave's first triangle: its runs in the sorted arrays start there
     const unsigned long long ok = __ballot(valid);
-    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    float4 r0 = zero4, r1 = zero4, r2 = zero4, r3 = zero4, r4 = zero4, r5 = zero4, r6 = zero4;
-    if (valid) {
-      const float4* rec = mesh_rec + (size_t)ti * MESH_REC;           // k_pack_mesh: the input triangle's attributes, two 64-byte sectors
-      r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3]; r4 = rec[4];
-      if (tri_uv) { r5 = rec[5]; r6 = rec[6]; }
-    }
     const V3 p[3] = {v3(r0.x, r0.y, r0.z), v3(r0.w, r1.x, r1.y), v3(r1.z, r1.w, r2.x)};
     const V3 nn[3] = {v3(r2.y, r2.z, r2.w), v3(r3.x, r3.y, r3.z), v3(r3.w, r4.x, r4.y)};
     {                                                  // web/script.js:530-545
@@ -886,7 +888,6 @@ __global__ __launch_bounds__(BLK) void k_refit_local(const float4* __restrict__ 
   __syncthreads();
   {
     const bool done = j + 1 < n_tri && s_visit[threadIdx.x] == 2u;   // internal node j was finished here: both children are in LDS
-    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     float4 w[4] = {zero4, zero4, zero4, zero4}, nd[2] = {zero4, zero4};
     if (done) {
       const int c0 = s_child[threadIdx.x][0], c1 = s_child[threadIdx.x][1];
