@@ -107,6 +107,8 @@ struct rt_ctx {
   RtBvhDev bvh;
   DevBuf<float> own_nodes, own_tri_pos, own_tri_nor;
   DevBuf<float4> wide, tri_pre;
+  DevBuf<float4> wide_paired;            // experiment (RTCORE_WIDE_PAIRED): see rt_launch_pair_wide
+  bool have_paired = false;
   bool have_bvh = false;
   int node_encoding = RT_NODES_V1;   // encoding of the next built / imported / adopted node buffer
 
@@ -291,7 +293,7 @@ extern "C" void rt_destroy(rt_ctx* ctx) {
   ctx->tile_counter.release(); ctx->words.release(); ctx->bounds_f.release(); ctx->centroids.release();
   ctx->span.release(); ctx->split.release(); ctx->mesh_rec.release(); ctx->cross_list.release(); ctx->refit_tables.release();
   ctx->own_nodes.release(); ctx->own_tri_pos.release(); ctx->own_tri_nor.release();
-  ctx->wide.release(); ctx->tri_pre.release();
+  ctx->wide.release(); ctx->tri_pre.release(); ctx->wide_paired.release();
   ctx->texcoords.release(); ctx->tri_uv.release(); ctx->tidx.release(); ctx->matid.release(); ctx->materials.release();
   for (auto& t : ctx->texels) t.release();
   ctx->tex_table.release();
@@ -370,7 +372,7 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
   JOIN_FRAMES();
   // the buffers of the previous BVH are reallocated / overwritten below: until this build has succeeded there is no BVH
   // (an early return must not leave have_bvh pointing at freed or half-written records)
-  ctx->have_bvh = false; ctx->built = false; ctx->tri_uv_n = 0;
+  ctx->have_bvh = false; ctx->built = false; ctx->tri_uv_n = 0; ctx->have_paired = false;
   hipStream_t s = ctx->stream;
   HIPCHK(ctx->bounds_enc.ensure(rt_bounds_words())); HIPCHK(ctx->bounds_f.ensure(8)); HIPCHK(ctx->centroids.ensure((size_t)T * 3));
   HIPCHK(ctx->codes.ensure(T)); HIPCHK(ctx->keys_a.ensure(T)); HIPCHK(ctx->keys_b.ensure(T));
@@ -427,6 +429,16 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
   ctx->tri_uv_n = ctx->surface_set ? T : 0;
   int rc = finish_bvh(ctx, /*packed_by_refit=*/true);
   if (rc != RT_OK) return rc;
+  if (getenv("RTCORE_WIDE_PAIRED") && T > 2) {      // experiment: built when the variable exists, used when it is "1" (rt_render*)
+    const uint32_t n_int = T - 1;
+    HIPCHK(ctx->wide_paired.ensure((size_t)2 * n_int * 4));
+    HIPCHK(hipMemsetAsync(ctx->words.p, 0, 4 * sizeof(uint32_t), s));
+    // up / pos borrow the sort's key buffers (free once the refit is done; T words each)
+    rt_launch_pair_wide(ctx->wide.p, n_int, ctx->keys_b.p, ctx->vals_b.p, ctx->words.p, ctx->wide_paired.p, s);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    ctx->have_paired = true;
+  }
   HIPCHK(hipEventRecord(ctx->ev[7], s));
   HIPCHK(hipEventSynchronize(ctx->ev[7]));
   ctx->built = true;
@@ -847,7 +859,9 @@ namespace {
 // surface tables.  alloc_tables = false: the no-alloc entry point, which must find the material / texture tables in place.
 int fill_scene_params(rt_ctx* ctx, const rt_render_opts* opts, RtRenderParams& p, bool alloc_tables) {
   p.nodes = ctx->bvh.nodes; p.tri_pos = ctx->bvh.tri_pos; p.tri_nor = ctx->bvh.tri_nor;
-  p.wide = ctx->bvh.wide; p.tri_pre = ctx->bvh.tri_pre; p.root_ref = ctx->bvh.root_ref; p.leaf_shift = ctx->bvh.leaf_shift;
+  p.wide = ctx->bvh.wide;
+  if (ctx->have_paired) { const char* e = getenv("RTCORE_WIDE_PAIRED"); if (e && e[0] == '1') p.wide = ctx->wide_paired.p; }
+  p.tri_pre = ctx->bvh.tri_pre; p.root_ref = ctx->bvh.root_ref; p.leaf_shift = ctx->bvh.leaf_shift;
   p.nodes_v2 = ctx->bvh.v2 ? 1 : 0;
   // one budget step per loop iteration of the walk: WIDE64 spends one per internal record AND one per leaf triangle
   // (closest_wide advances leaf_j one triangle per iteration), AOS32 one per node visit with twice this budget

@@ -1242,6 +1242,72 @@ void rt_launch_refit_upper(const RtBuildBuffers& b, float* nodes, float4* wide, 
                      t.mini_box, t.chunk_box, t.st, t.super_box, v2);
 }
 
+// ---------------------------------------------------------------- paired traversal table (experiment: RTCORE_WIDE_PAIRED)
+// Two tree levels per 128-byte line: a divergent fetch of a 64-byte record moves its whole line into the L1 anyway, so the
+// table is laid out as PAIRS {head, tail} = a node and that child of it a ray is most likely to enter (the internal child with
+// the larger surface).  Nothing but the records' positions changes (child references are translated to positions; leaf
+// references are untouched), so the traversal code, its results and its counters are the ones of `wide`.
+// A node is a tail iff the chain of "chosen" links that ends at it has odd length; every other internal node is a head.
+RT_DEV float half_area(float4 mn, float4 mx) {
+  const float dx = mx.x - mn.x, dy = mx.y - mn.y, dz = mx.z - mn.z;
+  return dx * dy + dy * dz + dz * dx;
+}
+__global__ __launch_bounds__(BLK) void k_pair_links(const float4* __restrict__ wide, uint32_t n_int, uint32_t* __restrict__ up) {
+  const uint32_t i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n_int) return;
+  const float4 q0 = wide[4 * (size_t)i + 0], q1 = wide[4 * (size_t)i + 1], q2 = wide[4 * (size_t)i + 2], q3 = wide[4 * (size_t)i + 3];
+  const uint32_t r0 = __float_as_uint(q0.w), r1 = __float_as_uint(q1.w);
+  const bool i0 = !(r0 & 0x80000000u), i1 = !(r1 & 0x80000000u);
+  const bool pick0 = i0 && (!i1 || half_area(q0, q1) >= half_area(q2, q3));
+  if (i0) up[r0] = (i << 1) | (pick0 ? 1u : 0u);
+  if (i1) up[r1] = (i << 1) | ((!pick0) ? 1u : 0u);
+  if (i == 0) up[0] = 0xFFFFFFFFu;
+}
+__global__ __launch_bounds__(BLK) void k_pair_heads(const uint32_t* __restrict__ up, uint32_t n_int, uint32_t* __restrict__ pos, uint32_t* counter) {
+  const uint32_t i = blockIdx.x * BLK + threadIdx.x;
+  bool head = false;
+  if (i < n_int) {
+    uint32_t j = i, len = 0;
+    while (j != 0 && (up[j] & 1u)) { len += 1; j = up[j] >> 1; }
+    head = (len & 1u) == 0u;
+  }
+  const unsigned long long m = __ballot(head && i != 0);
+  const int lane = threadIdx.x & 63;
+  uint32_t base = 0;
+  if (lane == 0 && m) base = atomicAdd(counter, (uint32_t)__popcll(m));
+  base = (uint32_t)__shfl((int)base, 0);
+  if (i < n_int) {
+    if (i == 0) pos[0] = 0u;                                       // the root's pair is the table's first line
+    else if (head) pos[i] = 2u * (1u + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
+    else pos[i] = 0xFFFFFFFFu;
+  }
+}
+__global__ __launch_bounds__(BLK) void k_pair_tails(const uint32_t* __restrict__ up, uint32_t n_int, uint32_t* __restrict__ pos) {
+  const uint32_t i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n_int || i == 0) return;
+  if (pos[i] == 0xFFFFFFFFu) pos[i] = pos[up[i] >> 1] + 1u;        // (its parent is a head: k_pair_heads, the launch before)
+}
+__global__ __launch_bounds__(BLK) void k_pair_permute(const float4* __restrict__ wide, uint32_t n_int, const uint32_t* __restrict__ pos, float4* __restrict__ paired) {
+  const uint32_t i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= n_int) return;
+  float4 q0 = wide[4 * (size_t)i + 0], q1 = wide[4 * (size_t)i + 1];
+  const float4 q2 = wide[4 * (size_t)i + 2], q3 = wide[4 * (size_t)i + 3];
+  const uint32_t r0 = __float_as_uint(q0.w), r1 = __float_as_uint(q1.w);
+  if (!(r0 & 0x80000000u)) q0.w = __uint_as_float(pos[r0]);
+  if (!(r1 & 0x80000000u)) q1.w = __uint_as_float(pos[r1]);
+  float4* o = paired + 4 * (size_t)pos[i];
+  o[0] = q0; o[1] = q1; o[2] = q2; o[3] = q3;
+}
+// up / pos: n_int words each; counter: one zeroed word; paired: 2 * n_int records (one pair per head at most)
+void rt_launch_pair_wide(const float4* wide, uint32_t n_int, uint32_t* up, uint32_t* pos, uint32_t* counter, float4* paired, hipStream_t s) {
+  if (n_int == 0) return;
+  const dim3 g((n_int + BLK - 1) / BLK), b(BLK);
+  hipLaunchKernelGGL(k_pair_links, g, b, 0, s, wide, n_int, up);
+  hipLaunchKernelGGL(k_pair_heads, g, b, 0, s, up, n_int, pos, counter);
+  hipLaunchKernelGGL(k_pair_tails, g, b, 0, s, up, n_int, pos);
+  hipLaunchKernelGGL(k_pair_permute, g, b, 0, s, wide, n_int, pos, paired);
+}
+
 // root_ref / err words live right behind the bounds words: see rt_api.hip (scratch[0], scratch[1])
 void rt_launch_pack_impl(const RtBvhDev& bvh, uint32_t* d_root_ref, uint32_t* d_err, hipStream_t s) {
   hipLaunchKernelGGL(k_pack_wide, dim3((bvh.n_nodes + BLK - 1) / BLK), dim3(BLK), 0, s, bvh.nodes, bvh.n_nodes, bvh.wide,

@@ -153,6 +153,8 @@ uint32_t rt_sort_tile_count(uint32_t n);
 size_t   rt_sort_status_words(uint32_t n);
 uint32_t rt_sort_hist_words();
 void rt_launch_bounds(const RtBuildBuffers& b, hipStream_t s);
+// experiment (RTCORE_WIDE_PAIRED): `wide` re-laid out as {node, likeliest child} pairs, one pair per 128-byte line
+void rt_launch_pair_wide(const float4* wide, uint32_t n_int, uint32_t* up, uint32_t* pos, uint32_t* counter, float4* paired, hipStream_t s);
 // mesh layout at upload: the indexed loadObj arrays de-indexed into one 128-byte record per triangle (tex_idx == NULL: no surface yet)
 size_t rt_mesh_rec_float4s(uint32_t n_tri);
 void rt_launch_pack_mesh(const float* pos, const float* nor, const uint32_t* vidx, const uint32_t* nidx, const float* texcoords,

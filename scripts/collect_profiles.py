@@ -75,6 +75,6 @@ elif len(ones) == 1:
     per_build["k_onesweep (x3)"] = 3 * per_build.pop(ones[0])
 bt = {"n_tri": n_tri, "algorithmic_bytes": 560 * n_tri, "fabric_bytes_per_build": per_build, "fabric_bytes_total": sum(per_build.values()),
       "ratio": round(sum(per_build.values()) / (560.0 * n_tri), 3),
-      "note": "surface records (48-byte index records, 32-byte tri_uv) are part of these builds but not of the 560 B/triangle figure"}
+      "note": "builds WITH surface records (texcoord / material slots of the 128-byte mesh records read, 32-byte tri_uv written): they are part of these bytes but not of the 560 B/triangle figure; like for like (no surface): build_traffic_nosurface.txt"}
 json.dump(bt, open(os.path.join(dst, "build_traffic.json"), "w"), indent=1)
 print("build fabric traffic / algorithmic:", bt["ratio"], per_build)

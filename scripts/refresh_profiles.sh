@@ -4,7 +4,7 @@
 set -e
 R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/refresh"; rm -rf "$O"; mkdir -p "$O"
 cd "$R"
-echo "[1] gpu tests"; timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > "$O/gpu_tests.log" 2>&1; tail -1 "$O/gpu_tests.log"
+echo "[1] gpu tests"; timeout -k 10 900 python -u -m pytest tests -m gpu -x -v --timeout 300 --timeout-method thread > "$O/gpu_tests.log" 2>&1; tail -1 "$O/gpu_tests.log"
 echo "[2] the driver's bench line"; timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 > "$O/bench_n1.json" 2> "$O/bench_n1.err"
 echo "[3] kernel trace"; scripts/kernel_stats.sh gpurun_out/refresh/ks > "$O/ks.txt" 2>&1; cd "$R"
 echo "[4] pmc passes (calibration kernels, then the bench)"
