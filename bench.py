@@ -454,11 +454,12 @@ def roofline(args, world, textured, batch, frames_per_launch, trav_ms, launch_by
               "l2_hit_rate": pmc.get("l2_hit_rate"), "valu_lane_util": pmc.get("valu_lane_util"), "ta_busy": pmc.get("ta_busy"),
               "valu_busy": pmc.get("valu_busy"), "wave_wait_share": pmc.get("wave_wait_share"), "shade": pmc.get("shade"),
               "traffic_source": pmc.get("source"),
+              "busiest_unit": max((("valu", pmc.get("valu_busy") or 0.0), ("vector_memory_address_unit", pmc.get("ta_busy") or 0.0)), key=lambda u: u[1])[0],
               "note": "frac = the busiest memory level's bytes / kernel time / that level's peak (levels: L2 hits vs 34.5 TB/s, L2 misses vs the "
-                      "8.6 TB/s random-row rate of the Infinity Cache, fabric bytes vs 8 TB/s HBM).  All three are far from their peaks: the kernel "
-                      "is bound by chains of dependent record fetches (a wave-step waits for its slowest lane: `wave_wait_share` of the wave cycles "
-                      "sit in s_waitcnt) with the VALU (`valu_busy` = 4 x SQ_INSTS_VALU / SIMD cycles) and the vector-memory address unit (`ta_busy`) "
-                      "as the busiest units; profiles/r3/README.md has the formulas"})
+                      "8.6 TB/s random-row rate of the Infinity Cache, fabric bytes vs 8 TB/s HBM).  All three are far from their peaks: no memory level "
+                      "bounds this kernel.  Its busiest unit is the VALU (`valu_busy` = 4 x SQ_INSTS_VALU / SIMD cycles, with `valu_lane_util` of the "
+                      "lanes doing work: box tests diverge inside a wave), then the vector-memory address unit (`ta_busy`); the waves spend "
+                      "`wave_wait_share` of their cycles waiting (chains of dependent record fetches).  profiles/r3/README.md has the formulas"})
     return r
 
 
