@@ -45,8 +45,7 @@ struct Scene {
   bool v2;                 // encoding of `nodes`
   int max_stack;
   uint32_t step_budget;    // > number of nodes: a valid tree never exhausts it; a cyclic (corrupt) import cannot hang the GPU
-  uint32_t* stk_ref;       // this thread's LDS column, stride TBLK
-  float*    stk_t;
+  uint2* stk;              // this thread's LDS column, stride TBLK: {reference, bits(entry distance)} - one 8-byte read per pop
   const float4* tri_uv;    // surface extension (rtcore.h "material / texture shading")
   const float4* materials;
   const RtTexDev* textures;
@@ -94,8 +93,8 @@ RT_DEV Hit closest_wide(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Wor
   auto pop = [&]() -> uint32_t {
     while (sp > 0) {
       sp -= 1;
-      const float tn = S.stk_t[sp * TBLK];
-      if (tn <= bestT) return S.stk_ref[sp * TBLK];   // re-test of compute.wgsl:275 with the stored entry distance
+      const uint2 e = S.stk[sp * TBLK];
+      if (__uint_as_float(e.y) <= bestT) return e.x;  // re-test of compute.wgsl:275 with the stored entry distance
     }
     return REF_DONE;
   };
@@ -124,8 +123,7 @@ RT_DEV Hit closest_wide(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Wor
       if (hit0 && hit1) {
         const bool first0 = (t0n <= t1n);              // compute.wgsl:310
         if (sp < S.max_stack - 1) {                    // :311 / :317 — otherwise the far child is dropped
-          S.stk_ref[sp * TBLK] = first0 ? r1 : r0;
-          S.stk_t[sp * TBLK] = first0 ? t1n : t0n;
+          S.stk[sp * TBLK] = make_uint2(first0 ? r1 : r0, __float_as_uint(first0 ? t1n : t0n));
           sp += 1;
         } else if (COUNT) W.drops += 1;
         cur = first0 ? r0 : r1;
@@ -227,7 +225,7 @@ RT_DEV Hit closest_aos(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Work
         const bool hit0 = box_hit(b0x, b0y, bestT), hit1 = box_hit(b1x, b1y, bestT);
         if (hit0 && hit1) {
           const bool first0 = (b0x <= b1x);
-          if (sp < S.max_stack - 1) { S.stk_ref[sp * TBLK] = (uint32_t)(first0 ? node.c1 : node.c0); sp += 1; }
+          if (sp < S.max_stack - 1) { S.stk[sp * TBLK].x = (uint32_t)(first0 ? node.c1 : node.c0); sp += 1; }
           else if (COUNT) W.drops += 1;
           cur = first0 ? node.c0 : node.c1;
         } else if (hit0) cur = node.c0;
@@ -236,7 +234,7 @@ RT_DEV Hit closest_aos(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Work
       }
     } else go_pop = true;
     if (go_pop) {
-      if (sp > 0) { sp -= 1; cur = (int)S.stk_ref[sp * TBLK]; } else break;
+      if (sp > 0) { sp -= 1; cur = (int)S.stk[sp * TBLK].x; } else break;
     }
   }
   Hit h; h.t = bestT; h.tri = bestTri; h.u = bu; h.v = bv; h.steps = 2u * S.step_budget - budget;
@@ -1118,8 +1116,7 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p, const B
   const unsigned long long tl_start = wall_clock64();
   unsigned long long tl_last = tl_start, tl_chunks = 0;
 #endif
-  uint32_t* stk_ref = reinterpret_cast<uint32_t*>(smem);
-  float* stk_t = reinterpret_cast<float*>(smem + sizeof(uint32_t) * (size_t)p.max_stack * TBLK);
+  uint2* stk = reinterpret_cast<uint2*>(smem);
 
   Scene S;
   S.nodes = reinterpret_cast<const float4*>(p.nodes);
@@ -1127,7 +1124,7 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p, const B
   S.tri_nor = reinterpret_cast<const float4*>(p.tri_nor);
   S.wide = p.wide; S.tri_pre = p.tri_pre;
   S.root_ref = p.root_ref; S.leaf_shift = p.leaf_shift; S.v2 = p.nodes_v2 != 0; S.max_stack = p.max_stack; S.step_budget = p.step_budget;
-  S.stk_ref = stk_ref + threadIdx.x; S.stk_t = stk_t + threadIdx.x;
+  S.stk = stk + threadIdx.x;
   S.tri_uv = p.tri_uv; S.materials = p.materials; S.textures = p.textures; S.n_materials = p.n_materials; S.n_textures = p.n_textures;
   Shade sh; sh.mode = p.mode; sh.gi_samples = p.gi_samples; sh.gi_bounces = p.gi_bounces; sh.soft_samples = p.soft_samples;
 
@@ -1332,15 +1329,14 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p, const B
 template <int LAYOUT, bool COUNT, bool TEX>
 __global__ __launch_bounds__(TBLK) void k_pt_samples(const RtRenderParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
-  uint32_t* stk_ref = reinterpret_cast<uint32_t*>(smem);
-  float* stk_t = reinterpret_cast<float*>(smem + sizeof(uint32_t) * (size_t)p.max_stack * TBLK);
+  uint2* stk = reinterpret_cast<uint2*>(smem);
   Scene S;
   S.nodes = reinterpret_cast<const float4*>(p.nodes);
   S.tri_pos = reinterpret_cast<const float4*>(p.tri_pos);
   S.tri_nor = reinterpret_cast<const float4*>(p.tri_nor);
   S.wide = p.wide; S.tri_pre = p.tri_pre;
   S.root_ref = p.root_ref; S.leaf_shift = p.leaf_shift; S.v2 = p.nodes_v2 != 0; S.max_stack = p.max_stack; S.step_budget = p.step_budget;
-  S.stk_ref = stk_ref + threadIdx.x; S.stk_t = stk_t + threadIdx.x;
+  S.stk = stk + threadIdx.x;
   S.tri_uv = p.tri_uv; S.materials = p.materials; S.textures = p.textures; S.n_materials = p.n_materials; S.n_textures = p.n_textures;
   Shade sh; sh.mode = p.mode; sh.gi_samples = p.gi_samples; sh.gi_bounces = p.gi_bounces; sh.soft_samples = p.soft_samples;
 
