@@ -98,6 +98,7 @@ struct rt_ctx {
   DevBuf<float> bounds_f, centroids;
   DevBuf<int32_t> span, split;
   DevBuf<float4> mesh_rec;
+  DevBuf<float> tri_in_pos;
   DevBuf<uint32_t> cross_list;
   DevBuf<float4> refit_tables;
   bool built = false;      // codes / order valid
@@ -291,7 +292,7 @@ extern "C" void rt_destroy(rt_ctx* ctx) {
   ctx->bounds_enc.release(); ctx->codes.release(); ctx->keys_a.release(); ctx->keys_b.release();
   ctx->vals_a.release(); ctx->vals_b.release(); ctx->hist.release(); ctx->tile_status.release();
   ctx->tile_counter.release(); ctx->words.release(); ctx->bounds_f.release(); ctx->centroids.release();
-  ctx->span.release(); ctx->split.release(); ctx->mesh_rec.release(); ctx->cross_list.release(); ctx->refit_tables.release();
+  ctx->span.release(); ctx->split.release(); ctx->mesh_rec.release(); ctx->tri_in_pos.release(); ctx->cross_list.release(); ctx->refit_tables.release();
   ctx->own_nodes.release(); ctx->own_tri_pos.release(); ctx->own_tri_nor.release();
   ctx->wide.release(); ctx->tri_pre.release(); ctx->wide_paired.release();
   ctx->texcoords.release(); ctx->tri_uv.release(); ctx->tidx.release(); ctx->matid.release(); ctx->materials.release();
@@ -353,7 +354,8 @@ extern "C" int rt_set_mesh(rt_ctx* ctx, const float* positions, uint32_t n_vert,
   // device layout of the mesh: de-indexed once, one 128-byte record per triangle (rt_build.hip k_pack_mesh); the records'
   // texcoord / material slots are filled by a later rt_set_surface
   HIPCHK(ctx->mesh_rec.ensure(rt_mesh_rec_float4s(n_tri)));
-  rt_launch_pack_mesh(ctx->pos.p, ctx->nor.p, ctx->vidx.p, ctx->nidx.p, nullptr, nullptr, nullptr, n_tri, ctx->mesh_rec.p, ctx->stream);
+  HIPCHK(ctx->tri_in_pos.ensure((size_t)n_tri * 9));
+  rt_launch_pack_mesh(ctx->pos.p, ctx->nor.p, ctx->vidx.p, ctx->nidx.p, nullptr, nullptr, nullptr, n_tri, ctx->mesh_rec.p, ctx->tri_in_pos.p, ctx->stream);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->n_vert = n_vert; ctx->n_nor = n_nor; ctx->n_tri_mesh = n_tri;
@@ -390,7 +392,7 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
   b.bounds_enc = ctx->bounds_enc.p; b.bounds_f = ctx->bounds_f.p; b.centroids = ctx->centroids.p; b.codes = ctx->codes.p;
   b.keys_a = ctx->keys_a.p; b.keys_b = ctx->keys_b.p; b.vals_a = ctx->vals_a.p; b.vals_b = ctx->vals_b.p;
   b.hist = ctx->hist.p; b.tile_status = ctx->tile_status.p; b.tile_counter = ctx->tile_counter.p;
-  b.err_flag = ctx->words.p + 2; b.span = ctx->span.p; b.split = ctx->split.p; b.mesh_rec = ctx->mesh_rec.p; b.cross_list = ctx->cross_list.p; b.refit_tables = ctx->refit_tables.p;
+  b.err_flag = ctx->words.p + 2; b.span = ctx->span.p; b.split = ctx->split.p; b.mesh_rec = ctx->mesh_rec.p; b.tri_in_pos = ctx->tri_in_pos.p; b.cross_list = ctx->cross_list.p; b.refit_tables = ctx->refit_tables.p;
   b.n_sort_tiles = rt_sort_tile_count(T);
   b.texcoords = nullptr; b.tex_idx = nullptr; b.material_ids = nullptr; b.tri_uv = nullptr;
   if (ctx->surface_set) {          // surface records into BVH order by the refit, next to triPos / triNor
@@ -693,7 +695,7 @@ extern "C" int rt_set_surface(rt_ctx* ctx, const float* texcoords, uint32_t n_te
   ctx->surface_has_mat = material_ids != nullptr;
   ctx->surface_set = true;
   rt_launch_pack_mesh(ctx->pos.p, ctx->nor.p, ctx->vidx.p, ctx->nidx.p, ctx->texcoords.p, ctx->tidx.p, ctx->surface_has_mat ? ctx->matid.p : nullptr, T,
-                      ctx->mesh_rec.p, s);                       // the records' texcoord / material slots
+                      ctx->mesh_rec.p, nullptr, s);              // the records' texcoord / material slots
   HIPCHK(hipGetLastError());
   if (ctx->built && ctx->have_bvh && ctx->bvh.n_tri == T) {   // the LBVH of this mesh already exists: reorder now
     HIPCHK(ctx->tri_uv.ensure((size_t)T * 8));

@@ -71,7 +71,7 @@ constexpr int MESH_REC = 8;       // float4 per record
 __global__ __launch_bounds__(BLK) void k_pack_mesh(const float* __restrict__ pos, const float* __restrict__ nor, const uint32_t* __restrict__ vidx,
                                                    const uint32_t* __restrict__ nidx, const float* __restrict__ texcoords,
                                                    const uint32_t* __restrict__ tex_idx, const int32_t* __restrict__ material_ids,
-                                                   uint32_t n_tri, float4* __restrict__ mesh_rec) {
+                                                   uint32_t n_tri, float4* __restrict__ mesh_rec, float* __restrict__ tri_in_pos /* [9T] or NULL */) {
   const uint32_t t = blockIdx.x * BLK + threadIdx.x;
   if (t >= n_tri) return;
   const V3 p0 = load_vtx(pos, vidx[3 * (size_t)t + 0]), p1 = load_vtx(pos, vidx[3 * (size_t)t + 1]), p2 = load_vtx(pos, vidx[3 * (size_t)t + 2]);
@@ -91,6 +91,10 @@ __global__ __launch_bounds__(BLK) void k_pack_mesh(const float* __restrict__ pos
   rec[4] = make_float4(n2.y, n2.z, a.x, a.y);
   rec[5] = make_float4(b.x, b.y, c.x, c.y);
   rec[6] = make_float4(__uint_as_float(mat), 0.0f, 0.0f, 0.0f);
+  if (tri_in_pos) {                                      // the positions once more, 36 bytes per triangle in input order: k_bounds streams them
+    float* q = tri_in_pos + 9 * (size_t)t;
+    q[0] = p0.x; q[1] = p0.y; q[2] = p0.z; q[3] = p1.x; q[4] = p1.y; q[5] = p1.z; q[6] = p2.x; q[7] = p2.y; q[8] = p2.z;
+  }
 }
 
 // ---------------------------------------------------------------- centroid bounds
@@ -101,13 +105,11 @@ __global__ __launch_bounds__(BLK) void k_pack_mesh(const float* __restrict__ pos
 // 1280 of them took 0.22 ms).
 // Also keeps every centroid (12 B/triangle, coalesced) so that k_morton streams them instead of repeating the
 // three-vertex gather through the index buffer (48 B/triangle of scattered reads).
-// The vertex gather is laid out per INDEX SLOT, not per triangle: lane l of a wave takes slots l, 64 + l, 128 + l of the wave's
-// 64 triangles (192 slots), so with the usual nearly-sequential index buffers one load instruction touches 6 lines instead
-// of 64 - the texture path handles ~4 cycles per line touched, and with one lane per triangle (3 vertices = 3 or 12 scattered
-// 12-byte loads per lane, every lane on its own lines) that rate, not HBM, set the kernel's time: 30 us at 1.3 M triangles,
-// 4.4 ms at 99.6 M.  The wave turns the slots into triangles through its own 2.3 KB of LDS.
+// Reads the de-indexed positions k_pack_mesh left at upload (36 bytes per triangle, streamed): through the index buffer every
+// vertex was a scattered 12-byte read that pulled a whole line - 30 us at 1.3 M triangles, and 4.4 ms at 99.6 M where a bare
+// stream of the same bytes takes 1.2 ms (tools/ubench_bounds).
 constexpr int BOUNDS_MAX_BLOCKS = 2048;
-__global__ __launch_bounds__(BLK) void k_bounds(const float* __restrict__ pos, const uint32_t* __restrict__ vidx,
+__global__ __launch_bounds__(BLK) void k_bounds(const float* __restrict__ tri_in_pos /* [9T], input order */,
                                                 uint32_t n_tri, uint32_t* part /* [6][gridDim.x] */,
                                                 float* __restrict__ centroids /* [3T] */,
                                                 uint32_t* __restrict__ hist, uint32_t* __restrict__ tile_counter) {
@@ -117,34 +119,28 @@ __global__ __launch_bounds__(BLK) void k_bounds(const float* __restrict__ pos, c
     if (threadIdx.x < 4) tile_counter[threadIdx.x] = 0u;
     for (int i = threadIdx.x; i < 64 * 32; i += BLK) tile_counter[32 + i] = 0u;      // the refit's lists of block-crossing nodes (CROSS_SHARDS x CROSS_STRIDE)
   }
-  __shared__ float s_vtx[BLK / 64][192 * 3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* win = s_vtx[wave];
   uint32_t mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u};
-  const size_t n_slots = 3 * (size_t)n_tri;
-  for (size_t t0 = ((size_t)blockIdx.x * (BLK / 64) + wave) * 64; t0 < n_tri; t0 += (size_t)gridDim.x * BLK) {   // the wave's 64 triangles
-    uint32_t ix[3];
+  constexpr int BU = 2;                                  // triangles per thread and step, their loads issued together
+  const size_t stride = (size_t)gridDim.x * BLK;
+  for (size_t t0 = (size_t)blockIdx.x * BLK + threadIdx.x; t0 < n_tri; t0 += BU * stride) {
+    V3 p[BU][3];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) { const size_t sl = 3 * t0 + 64 * r + lane; ix[r] = (sl < n_slots) ? vidx[sl] : 0u; }
-    V3 v[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) v[r] = load_vtx(pos, ix[r]);
-#pragma unroll
-    for (int r = 0; r < 3; ++r) { float* w = win + 3 * (64 * r + lane); w[0] = v[r].x; w[1] = v[r].y; w[2] = v[r].z; }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const size_t t = t0 + lane;
-    if (t < n_tri) {
-      const float* q = win + 9 * lane;
-      const V3 c = ((v3(q[0], q[1], q[2]) + v3(q[3], q[4], q[5])) + v3(q[6], q[7], q[8])) / 3.0f;   // web/morton_compute.wgsl:52, as tri_centroid
-      centroids[3 * t + 0] = c.x; centroids[3 * t + 1] = c.y; centroids[3 * t + 2] = c.z;
-      const uint32_t e[3] = {f2ord(c.x), f2ord(c.y), f2ord(c.z)};
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { mn[k] = min(mn[k], e[k]); mx[k] = max(mx[k], e[k]); }
+    for (int u = 0; u < BU; ++u) {
+      const size_t t = t0 + u * stride;
+      if (t < n_tri) { p[u][0] = load_vtx(tri_in_pos, 3 * t + 0); p[u][1] = load_vtx(tri_in_pos, 3 * t + 1); p[u][2] = load_vtx(tri_in_pos, 3 * t + 2); }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();                     // the window is rewritten by the next step
+#pragma unroll
+    for (int u = 0; u < BU; ++u) {
+      const size_t t = t0 + u * stride;
+      if (t < n_tri) {
+        const V3 c = ((p[u][0] + p[u][1]) + p[u][2]) / 3.0f;             // web/morton_compute.wgsl:52, as tri_centroid
+        centroids[3 * t + 0] = c.x; centroids[3 * t + 1] = c.y; centroids[3 * t + 2] = c.z;
+        const uint32_t e[3] = {f2ord(c.x), f2ord(c.y), f2ord(c.z)};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { mn[k] = min(mn[k], e[k]); mx[k] = max(mx[k], e[k]); }
+      }
+    }
   }
   __shared__ uint32_t s[6][BLK / 64];
 #pragma unroll
@@ -1158,14 +1154,14 @@ uint32_t rt_sort_hist_words() { return (uint32_t)(SORT_PASSES * RADIX); }
 uint32_t rt_bounds_words() { return 6u * BOUNDS_MAX_BLOCKS; }   // the block cap x 6 partials
 void rt_launch_bounds(const RtBuildBuffers& b, hipStream_t s) {
   const int g = grid_for(b.n_tri, BLK, BOUNDS_MAX_BLOCKS);           // = bounds_grid(n_tri): k_morton folds that many partials
-  hipLaunchKernelGGL(k_bounds, dim3(g), dim3(BLK), 0, s, b.pos, b.vidx, b.n_tri, b.bounds_enc, b.centroids, b.hist, b.tile_counter);
+  hipLaunchKernelGGL(k_bounds, dim3(g), dim3(BLK), 0, s, b.tri_in_pos, b.n_tri, b.bounds_enc, b.centroids, b.hist, b.tile_counter);
 }
 static int bounds_grid(uint32_t n_tri) { return grid_for(n_tri, BLK, BOUNDS_MAX_BLOCKS); }
 
 size_t rt_mesh_rec_float4s(uint32_t n_tri) { return (size_t)n_tri * MESH_REC; }
 void rt_launch_pack_mesh(const float* pos, const float* nor, const uint32_t* vidx, const uint32_t* nidx, const float* texcoords,
-                         const uint32_t* tex_idx, const int32_t* material_ids, uint32_t n_tri, float4* mesh_rec, hipStream_t s) {
-  hipLaunchKernelGGL(k_pack_mesh, dim3((n_tri + BLK - 1) / BLK), dim3(BLK), 0, s, pos, nor, vidx, nidx, texcoords, tex_idx, material_ids, n_tri, mesh_rec);
+                         const uint32_t* tex_idx, const int32_t* material_ids, uint32_t n_tri, float4* mesh_rec, float* tri_in_pos, hipStream_t s) {
+  hipLaunchKernelGGL(k_pack_mesh, dim3((n_tri + BLK - 1) / BLK), dim3(BLK), 0, s, pos, nor, vidx, nidx, texcoords, tex_idx, material_ids, n_tri, mesh_rec, tri_in_pos);
 }
 
 void rt_launch_morton(const RtBuildBuffers& b, hipStream_t s) {

@@ -132,6 +132,7 @@ struct RtBuildBuffers {
   uint32_t* bounds_enc;     // [rt_bounds_words()] per-block ordered-uint partials: min.xyz / max.xyz
   float*    bounds_f;       // [8] `Bounds` uniform: min.xyz,0, invExtent.xyz,0 (morton_compute.wgsl:3-6)
   float*    centroids;      // [3T] (p0 + p1 + p2) / 3 per input triangle, k_bounds -> k_morton
+  const float* tri_in_pos;  // [9T] the triangles' positions de-indexed, input order (k_pack_mesh, at upload): k_bounds streams them
   const float4* mesh_rec;   // [8T] the de-indexed mesh, one 128-byte record per input triangle (k_pack_mesh, at upload): positions, normals, texcoords, material
   uint32_t* codes;          // [T] unsorted Morton codes
   uint32_t* keys_a; uint32_t* keys_b;     // sort ping-pong
@@ -158,7 +159,7 @@ void rt_launch_pair_wide(const float4* wide, uint32_t n_int, uint32_t* up, uint3
 // mesh layout at upload: the indexed loadObj arrays de-indexed into one 128-byte record per triangle (tex_idx == NULL: no surface yet)
 size_t rt_mesh_rec_float4s(uint32_t n_tri);
 void rt_launch_pack_mesh(const float* pos, const float* nor, const uint32_t* vidx, const uint32_t* nidx, const float* texcoords,
-                         const uint32_t* tex_idx, const int32_t* material_ids, uint32_t n_tri, float4* mesh_rec, hipStream_t s);
+                         const uint32_t* tex_idx, const int32_t* material_ids, uint32_t n_tri, float4* mesh_rec, float* tri_in_pos /* NULL: leave as is */, hipStream_t s);
 void rt_launch_morton(const RtBuildBuffers& b, hipStream_t s);
 void rt_launch_sort(const RtBuildBuffers& b, hipStream_t s);      // result in keys_a / vals_a
 // also writes the traversal layout (wide, tri_pre) from the values it already holds: builds need no pack pass

@@ -62,8 +62,8 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ pos, const ui
   if (acc == 123.456f) sink[0] = acc;
 }
 
-int main() {
-  const uint32_t n = 1310720;
+int main(int argc, char** argv) {
+  const uint32_t n = argc > 1 ? (uint32_t)atol(argv[1]) : 1310720u;      // 99614720 = cfg 5
   std::vector<uint32_t> hi(3 * (size_t)n); for (size_t i = 0; i < hi.size(); ++i) hi[i] = (uint32_t)i;
   std::vector<float> hp(9 * (size_t)n); for (size_t i = 0; i < hp.size(); ++i) hp[i] = (float)(i % 977) * 0.001f;
   float *pos, *cen, *sink; uint32_t* idx; char* flush;
@@ -73,7 +73,7 @@ int main() {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int cold = 1; cold >= 0; --cold)
     for (int v = 0; v < 6; ++v) {
-      const int grid = (v == 1) ? (int)((n + 255) / 256) : (v == 4) ? (int)((n + 511) / 512) : 2048;
+      const int grid = (v == 1) ? (int)((n + 255) / 256) : (v == 4) ? (int)((n + 511) / 512) : (argc > 2 ? atoi(argv[2]) : 2048);
       float best = 1e9f, sum = 0.f; const int reps = 6;
       for (int r = 0; r < reps + 1; ++r) {
         if (cold) CK(hipMemsetAsync(flush, r, flush_bytes, 0));
