@@ -159,7 +159,10 @@ int rt_set_node_encoding(rt_ctx* ctx, int encoding);
 int rt_get_node_encoding(rt_ctx* ctx);   /* of the current BVH if there is one, else the setting */
 
 typedef struct rt_build_stats {
-  /* hipEvent times of the build's stages: ms_bounds = centroid bounds; ms_morton = codes + the sort's digit histograms;
+  /* ms_total = hipEvent time from the build's first launch to its last (+ ms_pack).  The stage fields are filled only after
+   * rt_set_build_stage_timing(ctx, 1) (0 otherwise): the events between the launches cost the build ~2 us each, so a build
+   * that reports its stages is ~3 % slower at 1.3 M triangles and its ms_total is the sum of the stages.
+   * hipEvent times of the build's stages: ms_bounds = centroid bounds; ms_morton = codes + the sort's digit histograms;
    * ms_sort = the three 10-bit onesweep passes; ms_refit = leaf records, triangle buffers and every node whose leaves
    * lie inside one 256-leaf block (Karras search + boxes, k_refit_local); ms_tree = the nodes that span blocks (their
    * Karras search and boxes, k_refit_mid + k_refit_spans); ms_pack = 0 for builds (the traversal records are written by
@@ -169,6 +172,8 @@ typedef struct rt_build_stats {
   uint64_t algorithmic_bytes;   /* 560 B x n_tri */
   uint32_t refit_fallbacks;     /* always 0 since round 2: the refit has no hand-off between workgroups left that could fail (kept for ABI stability) */
 } rt_build_stats;
+/* Per-stage build times on / off (default off; RTCORE_BUILD_STAGE_TIMES=0/1 overrides).  No counterpart in the reference. */
+int rt_set_build_stage_timing(rt_ctx* ctx, int on);
 
 /* Replaces buildLBVH(raw, 1) + flattenForSSBO (script.js:729-730) with the Morton LBVH the
  * reference only sketched (web/morton_compute.wgsl, compiled but never dispatched — F4):

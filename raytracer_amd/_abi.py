@@ -20,7 +20,7 @@ NODES_V1, NODES_V2 = 1, 2
 
 # every symbol include/rtcore.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
-    "rt_create", "rt_destroy", "rt_last_error", "rt_abi_version",
+    "rt_create", "rt_destroy", "rt_last_error", "rt_abi_version", "rt_set_build_stage_timing",
     "rt_mesh_load_obj", "rt_mesh_parse_obj", "rt_mesh_view_get", "rt_mesh_material", "rt_mesh_material_n_unknown", "rt_mesh_material_unknown", "rt_mesh_free",
     "rt_normalize_mesh", "rt_camera_default", "rt_make_uniforms",
     "rt_set_mesh", "rt_build_lbvh", "rt_get_bounds", "rt_get_morton", "rt_get_tri_order", "rt_get_counts",
@@ -144,6 +144,7 @@ def load():
         "rt_last_error": (cp, [vp]),
         "rt_debug_device_allocations": (C.c_uint64, []),
         "rt_abi_version": (C.c_int, []),
+        "rt_set_build_stage_timing": (C.c_int, [vp, C.c_int]),
         "rt_mesh_load_obj": (C.c_int, [cp, cp, C.POINTER(vp), C.c_char_p, C.c_size_t]),
         "rt_mesh_parse_obj": (C.c_int, [cp, C.c_size_t, cp, C.c_size_t, C.POINTER(vp), C.c_char_p, C.c_size_t]),
         "rt_mesh_view_get": (C.c_int, [vp, C.POINTER(MeshView)]),

@@ -108,6 +108,7 @@ struct rt_ctx {
   RtBvhDev bvh;
   DevBuf<float> own_nodes, own_tri_pos, own_tri_nor;
   DevBuf<float4> wide, tri_pre;
+  bool build_stage_times = false;        // rt_set_build_stage_timing
   DevBuf<float4> wide_paired;            // experiment (RTCORE_WIDE_PAIRED): see rt_launch_pair_wide
   bool have_paired = false;
   bool have_bvh = false;
@@ -364,6 +365,12 @@ extern "C" int rt_set_mesh(rt_ctx* ctx, const float* positions, uint32_t n_vert,
   return RT_OK;
 }
 
+extern "C" int rt_set_build_stage_timing(rt_ctx* ctx, int on) {
+  if (!ctx) return RT_ERR_INVALID;
+  ctx->build_stage_times = on != 0;
+  return RT_OK;
+}
+
 extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
   if (!ctx) return RT_ERR_INVALID;
   if (ctx->n_tri_mesh == 0) return ctx->fail(RT_ERR_INVALID, "rt_build_lbvh: call rt_set_mesh first");
@@ -402,15 +409,19 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
   }
 
   HIPCHK(hipMemsetAsync(ctx->words.p, 0, 4 * sizeof(uint32_t), s));
+  // per-stage hipEvents sit between the build's launches and cost it ~2 us each (0.279 -> 0.288 ms at 1.31 M triangles):
+  // recorded only on request (rt_set_build_stage_timing / RTCORE_BUILD_STAGE_TIMES=1), ms_total is always first launch -> last
+  bool stage_events = ctx->build_stage_times;
+  if (const char* e = getenv("RTCORE_BUILD_STAGE_TIMES")) stage_events = e[0] == '1';
   HIPCHK(hipEventRecord(ctx->ev[0], s));
   rt_launch_bounds(b, s);
-  HIPCHK(hipEventRecord(ctx->ev[1], s));
+  if (stage_events) HIPCHK(hipEventRecord(ctx->ev[1], s));
   rt_launch_morton(b, s);
-  HIPCHK(hipEventRecord(ctx->ev[2], s));
+  if (stage_events) HIPCHK(hipEventRecord(ctx->ev[2], s));
   rt_launch_sort(b, s);
-  HIPCHK(hipEventRecord(ctx->ev[3], s));
+  if (stage_events) HIPCHK(hipEventRecord(ctx->ev[3], s));
   rt_launch_refit_local(b, ctx->own_nodes.p, ctx->own_tri_pos.p, ctx->own_tri_nor.p, ctx->wide.p, ctx->tri_pre.p, v2, s);
-  HIPCHK(hipEventRecord(ctx->ev[4], s));
+  if (stage_events) HIPCHK(hipEventRecord(ctx->ev[4], s));
   rt_launch_refit_upper(b, ctx->own_nodes.p, ctx->wide.p, v2, s);
   HIPCHK(hipEventRecord(ctx->ev[5], s));
   HIPCHK(hipGetLastError());
@@ -446,13 +457,16 @@ extern "C" int rt_build_lbvh(rt_ctx* ctx, rt_build_stats* out) {
   ctx->built = true;
   if (out) {
     std::memset(out, 0, sizeof(*out));
+    if (stage_events) {
     (void)hipEventElapsedTime(&out->ms_bounds, ctx->ev[0], ctx->ev[1]);
     (void)hipEventElapsedTime(&out->ms_morton, ctx->ev[1], ctx->ev[2]);
     (void)hipEventElapsedTime(&out->ms_sort, ctx->ev[2], ctx->ev[3]);
     (void)hipEventElapsedTime(&out->ms_refit, ctx->ev[3], ctx->ev[4]);   // leaves + the tree and boxes inside every 256-leaf block
     (void)hipEventElapsedTime(&out->ms_tree, ctx->ev[4], ctx->ev[5]);    // the nodes above the blocks
-    (void)hipEventElapsedTime(&out->ms_pack, ctx->ev[6], ctx->ev[7]);
+    }
+    if (ctx->have_paired) (void)hipEventElapsedTime(&out->ms_pack, ctx->ev[6], ctx->ev[7]);   // else 0: a build launches nothing here (two events on an idle stream read ~4 us apart)
     out->ms_total = out->ms_bounds + out->ms_morton + out->ms_sort + out->ms_tree + out->ms_refit + out->ms_pack;
+    if (!stage_events) { float t = 0.0f; (void)hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[5]); out->ms_total = t + out->ms_pack; }   // the stage fields stay 0
     out->n_tri = T; out->n_nodes = N;
     out->algorithmic_bytes = 560ull * T;
     out->refit_fallbacks = ctx->refit_fallbacks;

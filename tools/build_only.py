@@ -22,8 +22,11 @@ ctx.set_mesh(m)
 if surface:
     ctx.set_surface(m)
 runs = [ctx.build_lbvh() for _ in range(n)]
+ctx.set_build_stage_timing(True)      # the stage breakdown from builds of its own (the events between launches cost ~2 us each)
+staged = [ctx.build_lbvh() for _ in range(max(4, n // 3))]
 keys = [k for k in runs[0] if k.startswith("ms_")]
-med = {k: float(np.median([r[k] for r in runs[2:]])) for k in keys}
+med = {k: float(np.median([r[k] for r in (runs if k in ("ms_total", "ms_pack") else staged)[2:]])) for k in keys}
+med["ms_total_with_stage_events"] = float(np.median([r["ms_total"] for r in staged[2:]]))
 print(name, m.n_tri, "triangles, median of", n - 2, "builds:", {k: round(v, 4) for k, v in med.items()},
       "frac", round(560.0 * m.n_tri / (med["ms_total"] * 1e-3) / 8e12, 4), flush=True)
 ctx.close()

@@ -15,6 +15,7 @@ from raytracer_amd import _abi, scenes
 ctx = rt.Context(0)
 m = rt.normalize_mesh(scenes.s1m())
 ctx.set_mesh(m)
+ctx.set_build_stage_timing(True)
 for _ in range(3):
     st = ctx.build_lbvh()
 L = C.CDLL(_abi.LIB_PATH)
