@@ -21,7 +21,10 @@ U = rt.make_uniforms(W, H, cam_pos=(0.0, 0.0, 1.3))
 import torch
 img = torch.zeros((H, W), dtype=torch.int32, device="cuda:0")
 opts = rt.render_opts(mode=mode, gi_samples=16)
-for _ in range(3):
+moving = len(sys.argv) > 2 and sys.argv[2] == "moving"      # the bench's per-frame leg: the model turns 1 degree per frame
+for k in range(12 if moving else 3):
+    if moving:
+        U = rt.make_uniforms(W, H, cam_pos=(0.0, 0.0, 1.3), rot_deg=(0.0, 1.0 * k, 0.0))
     st = ctx.render_device(U, opts, d_rgba8=img.data_ptr())
 L = C.CDLL(_abi.LIB_PATH)
 buf = np.zeros((4096 * 4, 4), np.uint64)
