@@ -82,6 +82,26 @@ def test_s70k(gpu_ctx, oracle):
     assert st["ms_total"] > 0
 
 
+def test_stage_times_are_opt_in(gpu_ctx, oracle):
+    """rt_build_stats: ms_total is always first launch -> last; the stage fields only after rt_set_build_stage_timing(ctx, 1)
+    (the events between the launches cost the build time), and the tree is the same either way."""
+    from raytracer_amd import scenes
+    mesh = scenes.s70k()
+    gpu_ctx.set_mesh(mesh)
+    st = gpu_ctx.build_lbvh()
+    stages = ("ms_bounds", "ms_morton", "ms_sort", "ms_tree", "ms_refit")
+    assert st["ms_total"] > 0 and all(st[k] == 0 for k in stages) and st["ms_pack"] == 0
+    plain = gpu_ctx.flatten_for_ssbo()["bvhData"].copy()
+    gpu_ctx.set_build_stage_timing(True)
+    try:
+        st2 = gpu_ctx.build_lbvh()
+        assert all(st2[k] > 0 for k in stages)
+        assert abs(st2["ms_total"] - sum(st2[k] for k in stages)) < 1e-4
+        assert np.array_equal(gpu_ctx.flatten_for_ssbo()["bvhData"].view(np.uint32), plain.view(np.uint32))
+    finally:
+        gpu_ctx.set_build_stage_timing(False)
+
+
 def test_sortedness_and_invariants_1m(gpu_ctx):
     """Full-size property checks (no oracle): sorted + stable, permutation, tree invariants, containment."""
     from raytracer_amd import scenes

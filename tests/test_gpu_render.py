@@ -194,3 +194,31 @@ def test_coherent_scheduling_changes_order_only(gpu_ctx, oracle, rt, plane_mesh)
             assert np.array_equal(out["rgba8"], ref2["rgba8"]) and np.array_equal(out["hit_tri"], ref2["hit_tri"])
     finally:
         gpu_ctx.set_coherent_scheduling(True)
+
+
+def test_paired_wide_table_changes_positions_only(rt, monkeypatch):
+    """RTCORE_WIDE_PAIRED (experiment): the traversal table re-laid out as {node, larger child} pairs per 128-byte
+    line.  Child references become table positions, nothing else: image, hit ids, distances and work counters are wide64's."""
+    import numpy as np
+    from raytracer_amd import scenes
+    mesh = rt.normalize_mesh(scenes.s70k())
+    U = rt.make_uniforms(320, 200, cam_pos=(0.0, 0.0, 1.3))
+    outs = {}
+    monkeypatch.setenv("RTCORE_WIDE_PAIRED", "0")      # present at build time: the paired table is built; "1" at render time: used
+    ctx = rt.Context(0)
+    try:
+        ctx.set_mesh(mesh)
+        ctx.build_lbvh()
+        for flag in ("0", "1"):
+            monkeypatch.setenv("RTCORE_WIDE_PAIRED", flag)
+            for mode, spp in ((rt.MODE_SHADOW, 32), (rt.MODE_PT, 4)):
+                outs[flag, mode] = ctx.render(U, rt.render_opts(mode=mode, gi_samples=spp, flags=rt.FLAG_COUNT_WORK))
+    finally:
+        ctx.close()
+    for mode in (rt.MODE_SHADOW, rt.MODE_PT):
+        (a, sa), (b, sb) = outs["0", mode], outs["1", mode]
+        for k in ("rgba8", "hit_tri", "hit_t"):
+            assert np.array_equal(a[k], b[k]), k
+        for k in ("box_tests", "tri_tests", "hit_updates", "rays_shadow", "rays_bounce", "stack_drops"):
+            assert sa[k] == sb[k], k
+        assert sa["box_tests"] > 0
