@@ -271,8 +271,11 @@ def main():
         t0 = time.perf_counter()
         ctx.profile_begin()
         run_frames(vs, n, per_frame)
+        t_enq = time.perf_counter()
         fence()
         e = time.perf_counter() - t0
+        if os.environ.get("RT_BENCH_TRACE"):
+            print(f"[bench trace] enqueue {1e3 * (t_enq - t0):.3f} ms, wait {1e3 * (time.perf_counter() - t_enq):.3f} ms, total {1e3 * e:.3f} ms", file=sys.stderr, flush=True)
         # per pipeline: all its kernels (cull, scan, compact, traversal) / the traversal launch / the shade launch (0 unless split)
         pipe_ms, trav_ms, shade_ms, launches = ctx.profile_end_phases()
         return e, pipe_ms, trav_ms, shade_ms, launches
