@@ -90,7 +90,8 @@ class GpuBackend:
     # ---- batches (BatchedFrames): B frames per pipeline, their exchange on a side stream
     def render_packed_batch(self, Us, opts, packed):
         """packed: [B, rows, width]; frame f of the batch goes to packed[f] (rt_render_batch_device, asynchronous)."""
-        self.ctx.render_batch_device(Us, opts, [packed[f].data_ptr() for f in range(len(Us))])
+        base, step = packed.data_ptr(), packed.stride(0) * packed.element_size()      # (one tensor call, not one per frame)
+        self.ctx.render_batch_device(Us, opts, [base + f * step for f in range(len(Us))])
 
     def side_stream(self):
         if self._side is None:
