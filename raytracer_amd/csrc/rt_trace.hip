@@ -1098,9 +1098,23 @@ extern "C" int rt_debug_timeline(unsigned long long* out, size_t n_words) {
 // what a lane does with its list entry.  TRAVERSE + SHADE are the two launches RT_MODE_PRIMARY / SHADOW frames run as: the
 // primary ray's walk alone (69 - 82 VGPRs: 5 - 6 waves per SIMD instead of the 3 of the whole pixel, and the launch's time follows
 // the number of resident waves: profiles/r3/ab_occupancy_lite.txt), then the colour of the pixels that hit something
+// Register caps (second __launch_bounds__ argument = waves per SIMD the compiler must make room for).  The launches of a batch
+// have no tail, their time follows the number of resident waves, and a few spilled registers cost less than a
+// missing wave: the whole-pixel kernel of a batch at <= 96 VGPRs (5 waves; 26 - 61 spilled) runs PT-16 batches in 2.54 ms per
+// frame instead of 3.31 and shadow batches in 0.255 instead of 0.314 (profiles/r3/ab_register_cap.txt; 4 waves: 2.79 / 0.269,
+// 6 waves: 2.59 / 0.273).  One frame per launch is as long as its longest chain whatever the occupancy: no cap there.
+#ifndef RT_PIXEL_BATCH_MIN_WAVES
+#define RT_PIXEL_BATCH_MIN_WAVES 5
+#endif
+#ifndef RT_SHADE_BATCH_MIN_WAVES
+#define RT_SHADE_BATCH_MIN_WAVES 5
+#endif
+#ifndef RT_PT_SAMPLES_MIN_WAVES
+#define RT_PT_SAMPLES_MIN_WAVES 1                  // (its grid is the PT-split launch's: a cap changed nothing, 3.56 / 3.56 / 3.61 ms at 1 / 4 / 5)
+#endif
 enum { KIND_PIXEL = 0, KIND_PTSPLIT = 1, KIND_FRAG_WEB = 2, KIND_FRAG_ROOT = 3, KIND_TRAVERSE = 4, KIND_SHADE = 5 };
 template <int LAYOUT, bool COUNT, bool TEX, int KIND, bool BATCH = false, typename B = RtNoBatch>
-__global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p, const B bt) {
+__global__ __launch_bounds__(TBLK, (LAYOUT != RT_LAYOUT_WIDE64) ? 1 : (BATCH && KIND == 0) ? RT_PIXEL_BATCH_MIN_WAVES : (BATCH && KIND == 5) ? RT_SHADE_BATCH_MIN_WAVES : 1) void k_render(const RtRenderParams p, const B bt) {
   constexpr bool PTSPLIT = KIND == KIND_PTSPLIT;
   constexpr bool SHADE = KIND == KIND_SHADE;
   static_assert(!BATCH || KIND == KIND_PIXEL || KIND == KIND_TRAVERSE || KIND == KIND_SHADE, "a batch runs the compute.wgsl pixel kind only");
@@ -1327,7 +1341,7 @@ __global__ __launch_bounds__(TBLK) void k_render(const RtRenderParams p, const B
 // giving the 64 lanes to 16 samples of 4 pixels instead was 25 % SLOWER than no split at all (incoherent gathers).
 // The bounce terms throughput * dS go to HBM (SoA, coalesced); part 3 adds them in the reference's order.
 template <int LAYOUT, bool COUNT, bool TEX>
-__global__ __launch_bounds__(TBLK) void k_pt_samples(const RtRenderParams p) {
+__global__ __launch_bounds__(TBLK, LAYOUT == RT_LAYOUT_WIDE64 ? RT_PT_SAMPLES_MIN_WAVES : 1) void k_pt_samples(const RtRenderParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   uint2* stk = reinterpret_cast<uint2*>(smem);
   Scene S;
@@ -1655,7 +1669,7 @@ void rt_launch_render_batch(const RtRenderParams& p_in, const RtBatch& bt, int l
   const void* shade = nullptr;
   if (two_phase) {
     shade = render_kernel(layout, count_work, tex, KIND_SHADE, true);
-    p2.render_blocks = resident_grid(n_cu, 0, shade, 4, "RTCORE_SHADE_BPC");
+    p2.render_blocks = resident_grid(n_cu, 0, shade, 5, "RTCORE_SHADE_BPC");
     if (p.blocks_per_cu_cap && !getenv("RTCORE_SHADE_BPC")) p2.render_blocks = std::min(p2.render_blocks, (uint32_t)n_cu * p.blocks_per_cu_cap);
     slots_b = p2.render_blocks * (TBLK / 64);
     p2.stats_partial = p.stats_partial ? p.stats_partial + (size_t)8 * bt.n * slots_a : nullptr;   // the shade phase's wave slots lie behind the traversal's
