@@ -1110,11 +1110,11 @@ extern "C" int rt_debug_timeline(unsigned long long* out, size_t n_words) {
 #define RT_SHADE_BATCH_MIN_WAVES 5
 #endif
 #ifndef RT_PT_SAMPLES_MIN_WAVES
-#define RT_PT_SAMPLES_MIN_WAVES 1                  // (its grid is the PT-split launch's: a cap changed nothing, 3.56 / 3.56 / 3.61 ms at 1 / 4 / 5)
+#define RT_PT_SAMPLES_MIN_WAVES 5                  // both launches of the per-frame PT split (KIND_PTSPLIT sizes the grid of both): PT-16 3.54 -> 3.34 ms per frame
 #endif
 enum { KIND_PIXEL = 0, KIND_PTSPLIT = 1, KIND_FRAG_WEB = 2, KIND_FRAG_ROOT = 3, KIND_TRAVERSE = 4, KIND_SHADE = 5 };
 template <int LAYOUT, bool COUNT, bool TEX, int KIND, bool BATCH = false, typename B = RtNoBatch>
-__global__ __launch_bounds__(TBLK, (LAYOUT != RT_LAYOUT_WIDE64) ? 1 : (BATCH && KIND == 0) ? RT_PIXEL_BATCH_MIN_WAVES : (BATCH && KIND == 5) ? RT_SHADE_BATCH_MIN_WAVES : 1) void k_render(const RtRenderParams p, const B bt) {
+__global__ __launch_bounds__(TBLK, (LAYOUT != RT_LAYOUT_WIDE64) ? 1 : (BATCH && KIND == 0) ? RT_PIXEL_BATCH_MIN_WAVES : (BATCH && KIND == 5) ? RT_SHADE_BATCH_MIN_WAVES : (KIND == 1) ? RT_PT_SAMPLES_MIN_WAVES : 1) void k_render(const RtRenderParams p, const B bt) {
   constexpr bool PTSPLIT = KIND == KIND_PTSPLIT;
   constexpr bool SHADE = KIND == KIND_SHADE;
   static_assert(!BATCH || KIND == KIND_PIXEL || KIND == KIND_TRAVERSE || KIND == KIND_SHADE, "a batch runs the compute.wgsl pixel kind only");
