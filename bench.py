@@ -193,10 +193,8 @@ def main():
     shade = dict(gi_samples=shade.gi_samples, gi_bounces=shade.gi_bounces, soft_samples=shade.soft_samples, max_stack=shade.max_stack)
     base = rt.render_opts(mode=mode, layout=layout, flags=tflag, **shade)
     # auto: 32 (RT_MAX_BATCH) on one GPU - K = 20 steps are ONE pipeline; 16 with N > 1, where two pipelines (10 + 10) let the
-    # exchange of the first overlap the traversal of the second; the older fragment shaders run one frame per pipeline
-    batch = (1 if frag else (32 if world == 1 else 16)) if args.batch == "auto" else int(args.batch)
-    if frag and batch > 1:
-        raise SystemExit("--batch > 1 renders through rt_render_batch_device: --mode primary|shadow|pt only")
+    # exchange of the first overlap the traversal of the second
+    batch = (32 if world == 1 else 16) if args.batch == "auto" else int(args.batch)
     # pipelines (frames, or batches of frames) in flight: 1 at N = 1, so that every k_render launch runs alone and its duration is
     # the kernel's own.  Batches stay at 1 with N > 1 too: a second batch in flight gains 5 % on a 1/8 share of a 4K frame and
     # loses 27 % on an 8K frame (each pipeline then owns 2 of the 3 resident blocks per CU); single frames use three

@@ -294,7 +294,7 @@ int rt_render_device_noalloc(rt_ctx* ctx, const float uniforms[44], const rt_ren
  * Per frame of a 32-frame batch against per-frame launches (one MI355X): 4K 0.44 -> 0.26 ms, 1080p 0.26 -> 0.064 ms.
  * (What differs between the frames - uniforms, output pointers - is copied into device memory ahead of the pipeline: the
  * uniforms and pointer arrays are free again when the call returns.)
- * RT_MODE_PRIMARY / SHADOW / PT only (PT runs one lane per pixel); with RT_FLAG_COUNT_WORK every frame's counters are kept
+ * Every mode (PT runs one lane per pixel; RT_MODE_FRAG_WEB / FRAG_ROOT as in rt_render_device: WIDE64, untextured); with RT_FLAG_COUNT_WORK every frame's counters are kept
  * (rt_batch_stats below; the counting instantiation is a few per cent slower, as for single frames); frames whose 44 uniforms
  * are byte-identical share one cull / compaction result (each is still traced and written in full);
  * asynchronous on rt_stream() - or, with rt_set_frames_in_flight(n >= 2), on the frame streams under the ordering rules

@@ -1134,7 +1134,10 @@ int render_batch(rt_ctx* ctx, uint32_t n_frames, const float* uniforms, const rt
   if (!uniforms) return ctx->fail(RT_ERR_INVALID, "uniforms are NULL");
   int rc = check_opts(ctx, opts);
   if (rc != RT_OK) return rc;
-  if (opts->mode > RT_MODE_PT) return ctx->fail(RT_ERR_INVALID, "rt_render_batch_device: RT_MODE_PRIMARY / SHADOW / PT only");
+  const int frag = opts->mode == RT_MODE_FRAG_WEB ? 1 : (opts->mode == RT_MODE_FRAG_ROOT ? 2 : 0);
+  if (opts->mode > RT_MODE_PT && !frag) return ctx->fail(RT_ERR_INVALID, "rt_render_batch_device: unknown mode");
+  if (frag && ((opts->flags & RT_FLAG_TEXTURED) || opts->layout != RT_LAYOUT_WIDE64))
+    return ctx->fail(RT_ERR_INVALID, "rt_render_batch_device: the fragment-shader modes take WIDE64 records and no RT_FLAG_TEXTURED (as rt_render_device)");
   const float fw = uniforms[36], fh = uniforms[37];
   if (!(fw >= 1.0f) || !(fh >= 1.0f) || fw > 65536.0f || fh > 65536.0f) return ctx->fail(RT_ERR_INVALID, "resolution out of range");
   RtBatch bt;
@@ -1164,7 +1167,8 @@ int render_batch(rt_ctx* ctx, uint32_t n_frames, const float* uniforms, const rt
   std::memcpy(p.U, uniforms, sizeof(float) * 44);               // (the kernels of a batch read bt.frames[f].U)
   p.mode = opts->mode; p.gi_samples = opts->gi_samples; p.gi_bounces = opts->gi_bounces; p.soft_samples = opts->soft_samples;
   p.max_stack = opts->max_stack;
-  p.miss_rgba = 0xFF000000u;
+  p.frag = frag;
+  p.miss_rgba = frag ? 0xFFFFCC99u : 0xFF000000u;               // as render_frame
   p.width = (uint32_t)fw; p.height = (uint32_t)fh;
   const bool striped = opts->stripe_rows > 0 && opts->stripe_world > 1;
   p.stripe_rows = striped ? opts->stripe_rows : 0; p.stripe_rank = striped ? opts->stripe_rank : 0;
@@ -1238,6 +1242,7 @@ int render_batch(rt_ctx* ctx, uint32_t n_frames, const float* uniforms, const rt
     RtRenderParams pf = p;
     std::memcpy(pf.U, uniforms + 44 * (size_t)f, sizeof(float) * 44);
     rt_cull_rect(pf, ctx->bvh.root_box);
+    if (frag) { const int y0 = (int)p.height - 1 - pf.cull_y1, y1 = (int)p.height - 1 - pf.cull_y0; pf.cull_y0 = y0; pf.cull_y1 = y1; }   // rows mirrored, as render_frame
     recs[f].cull[0] = pf.cull_x0; recs[f].cull[1] = pf.cull_x1; recs[f].cull[2] = pf.cull_y0; recs[f].cull[3] = pf.cull_y1;
   }
   HIPCHK(ctx->r_frames[slot].ensure(RT_MAX_BATCH));

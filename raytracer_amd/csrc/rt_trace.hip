@@ -1117,7 +1117,7 @@ template <int LAYOUT, bool COUNT, bool TEX, int KIND, bool BATCH = false, typena
 __global__ __launch_bounds__(TBLK, (LAYOUT != RT_LAYOUT_WIDE64) ? 1 : (BATCH && KIND == 0) ? RT_PIXEL_BATCH_MIN_WAVES : (BATCH && KIND == 5) ? RT_SHADE_BATCH_MIN_WAVES : (KIND == 1) ? RT_PT_SAMPLES_MIN_WAVES : 1) void k_render(const RtRenderParams p, const B bt) {
   constexpr bool PTSPLIT = KIND == KIND_PTSPLIT;
   constexpr bool SHADE = KIND == KIND_SHADE;
-  static_assert(!BATCH || KIND == KIND_PIXEL || KIND == KIND_TRAVERSE || KIND == KIND_SHADE, "a batch runs the compute.wgsl pixel kind only");
+  static_assert(!BATCH || KIND != KIND_PTSPLIT, "a batch runs PT one lane per pixel (no PT split)");
   constexpr int RPL = (RT_MAX_BATCH * N_CLASS + 63) / 64;   // runs (frame x cost class) of a batch's run table per lane
   constexpr int N_RUN = RPL * 64;
   // A work item of the queue: 64 list entries - one per lane - for every kind but SHADE.  The shade launch takes SHADE_G x 64
@@ -1504,6 +1504,8 @@ static const void* render_kernel_lcx(int layout, bool count, bool tex) {
 }
 // frag kinds: WIDE64 records, constant albedo (rt_render_device rejects anything else); a batch: the pixel kind only
 static const void* render_kernel(int layout, bool count, bool tex, int kind, bool batch) {
+  if (kind == KIND_FRAG_WEB && batch) return count ? render_kernel_ptr<RT_LAYOUT_WIDE64, true, false, KIND_FRAG_WEB, true>() : render_kernel_ptr<RT_LAYOUT_WIDE64, false, false, KIND_FRAG_WEB, true>();
+  if (kind == KIND_FRAG_ROOT && batch) return count ? render_kernel_ptr<RT_LAYOUT_WIDE64, true, false, KIND_FRAG_ROOT, true>() : render_kernel_ptr<RT_LAYOUT_WIDE64, false, false, KIND_FRAG_ROOT, true>();
   if (kind == KIND_FRAG_WEB) return count ? render_kernel_ptr<RT_LAYOUT_WIDE64, true, false, KIND_FRAG_WEB, false>() : render_kernel_ptr<RT_LAYOUT_WIDE64, false, false, KIND_FRAG_WEB, false>();
   if (kind == KIND_FRAG_ROOT) return count ? render_kernel_ptr<RT_LAYOUT_WIDE64, true, false, KIND_FRAG_ROOT, false>() : render_kernel_ptr<RT_LAYOUT_WIDE64, false, false, KIND_FRAG_ROOT, false>();
   if (kind == KIND_PTSPLIT) return render_kernel_lcx<KIND_PTSPLIT, false>(layout, count, tex);
@@ -1654,8 +1656,10 @@ void rt_launch_render_batch(const RtRenderParams& p_in, const RtBatch& bt, int l
   RtBatch batch = bt;
   const dim3 b(TBLK), gc(rt_cull_blocks(p.n_tiles), bt.n);
   const bool tex = p.tri_uv != nullptr;
-  const bool two_phase = p.hits != nullptr && p.mode != RT_MODE_PT;      // as rt_launch_render
-  const void* kernel = two_phase ? render_kernel(layout, count_work, false, KIND_TRAVERSE, true) : render_kernel(layout, count_work, tex, KIND_PIXEL, true);
+  const bool two_phase = p.hits != nullptr && p.mode != RT_MODE_PT && !p.frag;      // as rt_launch_render
+  const int kind = p.frag == 1 ? KIND_FRAG_WEB : p.frag == 2 ? KIND_FRAG_ROOT : KIND_PIXEL;
+  if (p.frag) layout = RT_LAYOUT_WIDE64;
+  const void* kernel = two_phase ? render_kernel(layout, count_work, false, KIND_TRAVERSE, true) : render_kernel(layout, count_work, tex && !p.frag, kind, true);
   // the traversal launch: 5 blocks per CU (of the 6 that fit) - 4 / 5 / 6: 0.254 / 0.234 / 0.239 ms per frame with the shade launch at 4
   p.render_blocks = resident_grid(n_cu, p.max_stack, kernel, two_phase ? 5 : 0, two_phase ? "RTCORE_TRAVERSE_BPC" : "RTCORE_BLOCKS_PER_CU");
   if (p.blocks_per_cu_cap && !getenv("RTCORE_BLOCKS_PER_CU")) p.render_blocks = std::min(p.render_blocks, (uint32_t)n_cu * p.blocks_per_cu_cap);   // pipelines in flight share the CUs

@@ -403,7 +403,7 @@ class BatchedFrames:
         self.streams = hasattr(backend, "exchange_batch")
         # Only the union of the frames' screen rectangles is exchanged (the rest of every frame is background, known without
         # sending it): cfg 3's camera, 9 MB instead of 33 MB per frame.  Every rank derives the same window from the uniforms.
-        self.windowed = bool(window_exchange) and self.collective and hasattr(backend, "exchange_batch_window")
+        self.windowed = bool(window_exchange) and self.collective and hasattr(backend, "exchange_batch_window") and o.mode <= 2   # (the fragment modes' rectangle is mirrored: whole stripes, as ShardedFrame)
         self.staging_ring = [backend.alloc(batch * self.rpr, width) for _ in range(2)] if self.windowed else None
         self.window = [None, None]     # per buffer set: ((col0, n_cols, group0, n_rows), fill)
 

@@ -167,8 +167,11 @@ def test_batch_rejects_what_it_does_not_define(rt, plane_mesh):
             ctx.batch_stats(3)                                           # that batch had 2 frames
         assert e.value.code == -1
         assert len(ctx.batch_stats(2)) == 2
+        with pytest.raises(rt.RtError) as e:                              # the fragment modes: WIDE64 and untextured only, as for single frames
+            ctx.render_batch_device(np.stack([U, U]), rt.render_opts_for_mode(rt.MODE_FRAG_WEB, flags=rt.FLAG_TEXTURED), None, None, None)
+        assert e.value.code == -1
         with pytest.raises(rt.RtError) as e:
-            ctx.render_batch_device(np.stack([U, U]), rt.render_opts_for_mode(rt.MODE_FRAG_WEB), None, None, None)
+            ctx.render_batch_device(np.stack([U, U]), rt.render_opts(mode=9), None, None, None)
         assert e.value.code == -1
     finally:
         ctx.close()

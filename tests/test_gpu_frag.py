@@ -69,3 +69,32 @@ def test_frag_argument_errors(gpu_ctx, rt, plane_mesh):
             gpu_ctx.render(U, rt.render_opts_for_mode(rt.MODE_FRAG_WEB, **bad))
     with pytest.raises(rt.RtError):
         gpu_ctx.render(U, rt.render_opts_for_mode(rt.MODE_FRAG_ROOT, gi_samples=17))
+
+
+@pytest.mark.parametrize("mode", ["web", "root"])
+def test_frag_batches_equal_single_frames(gpu_ctx, rt, plane_mesh, mode):
+    """rt_render_batch_device with the fragment-shader modes: frame f of a batch = rt_render_device of its uniforms, bit for bit
+    (image, hit ids, distances) and counter for counter; views differ (the mirrored cull rectangle is per frame)."""
+    import torch
+    gpu_ctx.set_mesh(plane_mesh)
+    gpu_ctx.build_lbvh()
+    w, h, n = 160, 96, 5
+    Us = np.stack([rt.make_uniforms(w, h, cam_pos=(0.15 * k - 0.3, 0.2 * k - 0.4, 1.3 + 0.1 * k), rot_deg=(-90.0, 7.0 * k, 0.0),
+                                    scale=(2.5, 2.5, 2.5)) for k in range(n)])
+    o = rt.render_opts_for_mode(MODES[mode], gi_samples=4, gi_bounces=2, soft_samples=3, flags=rt.FLAG_COUNT_WORK)
+    dev = torch.device("cuda:0")
+    buf = {k: torch.zeros((n, h, w), dtype=dt, device=dev) for k, dt in (("rgba8", torch.int32), ("hit_tri", torch.int32), ("hit_t", torch.float32))}
+    gpu_ctx.render_batch_device(Us, o, *[[buf[k][f].data_ptr() for f in range(n)] for k in ("rgba8", "hit_tri", "hit_t")])
+    stats = gpu_ctx.batch_stats(n)
+    hits = 0
+    for f in range(n):
+        ref, st = gpu_ctx.render(Us[f], o)
+        assert np.array_equal(buf["rgba8"][f].cpu().numpy().view(np.uint8).reshape(h, w, 4), ref["rgba8"]), f
+        assert np.array_equal(buf["hit_tri"][f].cpu().numpy().view(np.uint32), ref["hit_tri"]), f
+        assert np.array_equal(buf["hit_t"][f].cpu().numpy(), ref["hit_t"]), f
+        for k in COUNT_KEYS:
+            assert stats[f][k] == st[k], (f, k)
+        hits += int((ref["hit_tri"] != 0xFFFFFFFF).sum())
+    assert hits > 1000
+    with pytest.raises(rt.RtError):
+        gpu_ctx.render_batch_device(Us, rt.render_opts_for_mode(MODES[mode], layout=rt.LAYOUT_AOS32), [buf["rgba8"][f].data_ptr() for f in range(n)])
