@@ -1200,8 +1200,12 @@ int render_batch(rt_ctx* ctx, uint32_t n_frames, const float* uniforms, const rt
   bt.bt_stride = rt_n_class() * cull_blocks;
   bt.list_stride = (uint32_t)list_words;
   bt.lc_stride = RT_LC_WORDS;
-  bool two_phase = opts->mode == RT_MODE_PRIMARY || opts->mode == RT_MODE_SHADOW;
-  if (const char* e = std::getenv("RTCORE_TWO_PHASE")) two_phase = two_phase && std::atoi(e) != 0;
+  // The traverse / shade split (two launches) is an option, not the default: what it bought was occupancy, and the whole-pixel
+  // kernel capped at 96 VGPRs reaches the same 5 waves per SIMD in ONE launch - as fast on whole frames (0.2339 / 0.2350 against
+  // 0.2385 / 0.2373 ms per frame) and 8 - 11 % faster on stripe shares, where the second launch is a second tail
+  // (profiles/r3/ab_register_cap.txt, project_scaling_*.txt).  RTCORE_TWO_PHASE=1 selects the split.
+  bool two_phase = false;
+  if (const char* e = std::getenv("RTCORE_TWO_PHASE")) two_phase = std::atoi(e) != 0 && (opts->mode == RT_MODE_PRIMARY || opts->mode == RT_MODE_SHADOW);
   const size_t tc_words = 2 * (size_t)rt_shard_words() + (size_t)RT_LC_WORDS * n_frames + (size_t)bt.bt_stride * n_frames;
   const size_t st_words = 8 + 32 + (size_t)bt.mask_stride * n_frames;
   HIPCHK(ctx->r_tile_counter[slot].ensure(tc_words));
@@ -1364,6 +1368,7 @@ extern "C" int rt_profile_end_phases(rt_ctx* ctx, float* ms_frame_avg, float* ms
     HIPCHK(hipEventElapsedTime(&a, E[0], E[3]));
     HIPCHK(hipEventElapsedTime(&b, E[1], E[4]));
     HIPCHK(hipEventElapsedTime(&c, E[4], E[2]));
+    if (c < 0.004f) { b += c; c = 0.f; }           // nothing was launched between the two events (no second phase): two records ~2 us apart
     fsum += a; tsum += b; ssum += c;
   }
   if (ms_frame_avg) *ms_frame_avg = n ? (float)(fsum / n) : 0.f;

@@ -27,9 +27,14 @@ with open(os.path.join(src, "gpu_tests.log")) as f:
     open(os.path.join(dst, "gpu_tests.log"), "w").write("".join(f.readlines()[-3:]))
 allk = json.load(open(os.path.join(src, "traffic_all.json")))
 K = 20                                         # bench.py --steps 20: the LAST dispatch of the batch kernels in every pass is the timed pipeline of 20 frames
-trav = [k for k in allk if k.startswith("k_render<0, false, false, 4, true")]      # WIDE64, no counters, KIND_TRAVERSE, batch
-shade = [k for k in allk if k.startswith("k_render<0, false, true, 5, true")]      # WIDE64, no counters, textured, KIND_SHADE, batch
-assert len(trav) == 1 and len(shade) == 1, list(allk)
+# the batch pipeline's traversal kernel: the whole-pixel kernel (WIDE64, no counters, textured, KIND_PIXEL, batch) - or, with
+# RTCORE_TWO_PHASE=1, KIND_TRAVERSE + KIND_SHADE
+trav = [k for k in allk if k.startswith("k_render<0, false, false, 4, true")]
+shade = [k for k in allk if k.startswith("k_render<0, false, true, 5, true")]
+if not trav:
+    trav = [k for k in allk if k.startswith("k_render<0, false, true, 0, true")]
+    shade = []
+assert len(trav) == 1 and len(shade) <= 1, list(allk)
 
 
 def per_frame(name):
@@ -47,7 +52,7 @@ t = {"workload": {"scene": "s1m", "width": 3840, "height": 2160, "mode": "shadow
      "conversion": "L2 bytes = TCC_HIT_sum / TCC_MISS_sum x 128 B (one request = one 128-byte line: profiles/" + RND + "/pmc_calib.txt, 1 GiB streamed = "
                    "8.389 M requests); fabric bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (MI355X_MICROARCH.md, HBM / rocprofv3: gfx950 FETCH_SIZE reports "
                    "half of the bytes read; Infinity-Cache hits are counted in it, so it is an upper bound on HBM bytes)",
-     "k_render": dict(per_frame(trav[0]), shade=per_frame(shade[0])),
+     "k_render": dict(per_frame(trav[0]), **({"shade": per_frame(shade[0])} if shade else {})),
      "all_kernels_fabric_bytes_per_launch": {k: v["derived_mean"]["fabric_bytes"] for k, v in sorted(allk.items()) if "fabric_bytes" in v.get("derived_mean", {})}}
 json.dump(t, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 b = json.loads(open(os.path.join(dst, "bench_n1.json")).read().strip().splitlines()[-1])

@@ -19,7 +19,7 @@ b primary --mode primary --no-legs
 b aos32 --layout aos32 --no-legs
 b pt16 --mode pt --spp 16 --steps 10 --no-legs
 b s70k_1080p --scene s70k --width 1920 --height 1080 --mode primary
-RTCORE_TWO_PHASE=0 b one_launch_per_pixel --no-legs
+RTCORE_TWO_PHASE=1 b traverse_shade_split --no-legs
 echo "[6] cfg 5"; timeout -k 10 500 python bench.py --no-cpu-baseline --no-legs --scene lattice76 --width 7680 --height 4320 --steps 10 > "$O/bench_cfg5_100Mtri_8k.json" 2> "$O/bench_cfg5.err"
 echo "[7] frag"; b frag_root --mode frag-root --steps 10 --no-legs; b frag_web --mode frag-web --steps 5 --no-legs
 echo "[8] build kernels"; scripts/build_stats.sh gpurun_out/refresh/build s1m 20 > "$O/build_stats.txt" 2>&1; cd "$R"

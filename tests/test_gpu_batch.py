@@ -9,6 +9,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 PLANE_VIEW = dict(cam_pos=(0.0, 0.0, 1.3), rot_deg=(-90.0, 0.0, 0.0), scale=(2.5, 2.5, 2.5))
+COUNT_KEYS = ("rays_primary", "rays_shadow", "rays_bounce", "box_tests", "tri_tests", "hit_updates", "pixels", "stack_drops", "pixels_traced")
 
 
 def _bufs(torch, n, rows, w):
@@ -137,6 +138,42 @@ def test_batch_equals_per_frame_rendering(rt, oracle):
         ctx.close()
 
 
+def test_traverse_shade_split_is_the_same_frames(rt, monkeypatch):
+    """RTCORE_TWO_PHASE=1: RT_MODE_PRIMARY / SHADOW batches as two launches (the primary rays' walk, then the colour of the hits
+    compacted per work item).  Not the default any more (a register cap gives the one-launch kernel the same occupancy), kept as
+    an option: same images, hit ids, distances and per-frame counters."""
+    import torch
+    from raytracer_amd import scenes
+    mesh = rt.normalize_mesh(scenes.s70k())
+    ctx = rt.Context(0)
+    try:
+        ctx.set_mesh(mesh)
+        ctx.set_surface(mesh)
+        ctx.build_lbvh()
+        ctx.set_materials(scenes.STANDIN_MATERIALS)
+        ctx.set_texture(0, scenes.procedural_texture(256, 0))
+        ctx.set_texture(1, scenes.procedural_texture(128, 1))
+        Us = _views(rt, 483, 271, 6)
+        n = len(Us)
+        for opts, rows in ((rt.render_opts(mode=rt.MODE_SHADOW, flags=rt.FLAG_TEXTURED | rt.FLAG_COUNT_WORK), None),
+                           (rt.render_opts(mode=rt.MODE_PRIMARY, flags=rt.FLAG_COUNT_WORK), None),
+                           (rt.render_opts(mode=rt.MODE_SHADOW, flags=rt.FLAG_COUNT_WORK, stripe_rows=16, stripe_rank=1, stripe_world=3), rt.packed_rows(271, 16, 1, 3))):
+            monkeypatch.setenv("RTCORE_TWO_PHASE", "0")
+            one = _batch(ctx, torch, Us, opts, rows=rows)
+            st_one = ctx.batch_stats(n)
+            monkeypatch.setenv("RTCORE_TWO_PHASE", "1")
+            two = _batch(ctx, torch, Us, opts, rows=rows)
+            st_two = ctx.batch_stats(n)
+            _same(two, one, f"split vs one launch, mode {opts.mode}")
+            for f in range(n):
+                for k in COUNT_KEYS:
+                    assert st_one[f][k] == st_two[f][k], (f, k)
+            assert sum(s["rays_primary"] for s in st_one) > 0
+    finally:
+        monkeypatch.delenv("RTCORE_TWO_PHASE", raising=False)
+        ctx.close()
+
+
 def test_batch_rejects_what_it_does_not_define(rt, plane_mesh):
     ctx = rt.Context(0)
     try:
@@ -175,9 +212,6 @@ def test_batch_rejects_what_it_does_not_define(rt, plane_mesh):
         assert e.value.code == -1
     finally:
         ctx.close()
-
-
-COUNT_KEYS = ("rays_primary", "rays_shadow", "rays_bounce", "box_tests", "tri_tests", "hit_updates", "pixels", "stack_drops", "pixels_traced")
 
 
 def test_batch_counters_equal_the_oracle_per_frame(rt, oracle):
