@@ -1368,7 +1368,7 @@ extern "C" int rt_profile_end_phases(rt_ctx* ctx, float* ms_frame_avg, float* ms
     HIPCHK(hipEventElapsedTime(&a, E[0], E[3]));
     HIPCHK(hipEventElapsedTime(&b, E[1], E[4]));
     HIPCHK(hipEventElapsedTime(&c, E[4], E[2]));
-    if (c < 0.004f) { b += c; c = 0.f; }           // nothing was launched between the two events (no second phase): two records ~2 us apart
+    if (c < 0.02f) { b += c; c = 0.f; }            // nothing was launched between the two events (no second phase): two records 2 - 5 us apart
     fsum += a; tsum += b; ssum += c;
   }
   if (ms_frame_avg) *ms_frame_avg = n ? (float)(fsum / n) : 0.f;

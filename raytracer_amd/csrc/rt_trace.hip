@@ -1114,7 +1114,7 @@ extern "C" int rt_debug_timeline(unsigned long long* out, size_t n_words) {
 #endif
 enum { KIND_PIXEL = 0, KIND_PTSPLIT = 1, KIND_FRAG_WEB = 2, KIND_FRAG_ROOT = 3, KIND_TRAVERSE = 4, KIND_SHADE = 5 };
 template <int LAYOUT, bool COUNT, bool TEX, int KIND, bool BATCH = false, typename B = RtNoBatch>
-__global__ __launch_bounds__(TBLK, (LAYOUT != RT_LAYOUT_WIDE64) ? 1 : (BATCH && KIND == 0) ? RT_PIXEL_BATCH_MIN_WAVES : (BATCH && KIND == 5) ? RT_SHADE_BATCH_MIN_WAVES : (KIND == 1) ? RT_PT_SAMPLES_MIN_WAVES : 1) void k_render(const RtRenderParams p, const B bt) {
+__global__ __launch_bounds__(TBLK, (BATCH && KIND == 0) ? RT_PIXEL_BATCH_MIN_WAVES : (LAYOUT != RT_LAYOUT_WIDE64) ? 1 : (BATCH && KIND == 5) ? RT_SHADE_BATCH_MIN_WAVES : (KIND == 1) ? RT_PT_SAMPLES_MIN_WAVES : 1) void k_render(const RtRenderParams p, const B bt) {
   constexpr bool PTSPLIT = KIND == KIND_PTSPLIT;
   constexpr bool SHADE = KIND == KIND_SHADE;
   static_assert(!BATCH || KIND != KIND_PTSPLIT, "a batch runs PT one lane per pixel (no PT split)");

@@ -20,11 +20,13 @@ for f in glob.glob(os.path.join(src, "bench_*.json")):
     json.loads(line[-1])
     shutil.copy(f, os.path.join(dst, os.path.basename(f)))
 shutil.copy(os.path.join(src, "ks", "kernel_stats.csv"), os.path.join(dst, "kernel_stats.csv"))
+for f in glob.glob(os.path.join(src, "project_scaling_*.txt")):
+    if os.path.getsize(f) > 0:
+        shutil.copy(f, os.path.join(dst, os.path.basename(f)))
 for f in ("pmc_summary.txt", "pmc_calib.txt"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
-with open(os.path.join(src, "gpu_tests.log")) as f:
-    open(os.path.join(dst, "gpu_tests.log"), "w").write("".join(f.readlines()[-3:]))
+shutil.copy(os.path.join(src, "gpu_tests.log"), os.path.join(dst, "gpu_tests.log"))      # the -v log: every test by name
 allk = json.load(open(os.path.join(src, "traffic_all.json")))
 K = 20                                         # bench.py --steps 20: the LAST dispatch of the batch kernels in every pass is the timed pipeline of 20 frames
 # the batch pipeline's traversal kernel: the whole-pixel kernel (WIDE64, no counters, textured, KIND_PIXEL, batch) - or, with

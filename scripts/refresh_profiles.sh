@@ -29,4 +29,8 @@ scripts/build_pmc.sh gpurun_out/refresh/build_pmc > "$O/build_traffic_nosurface.
 echo "[9] N > 1 rehearsal on this one GPU (gloo through host memory: code path only, not a measurement)"
 scripts/rehearse_multi.sh 2 4 > "$O/rehearsal.txt" 2>&1 || true
 for n in 2 4; do [ -f "$R/gpurun_out/rehearse/bench_n$n.json" ] && tail -1 "$R/gpurun_out/rehearse/bench_n$n.json" > "$O/rehearsal_n$n.json"; done
+echo "[10] per-rank projection of the N > 1 loop on this one GPU (tools/project_scaling.py)"
+PROJ_BATCH=16 timeout -k 10 300 python tools/project_scaling.py 2>&1 | grep "^N=" > "$O/project_scaling_batch16.txt" || true
+RTCORE_TWO_PHASE=1 PROJ_BATCH=16 timeout -k 10 300 python tools/project_scaling.py 2>&1 | grep "^N=" > "$O/project_scaling_batch16_split.txt" || true
+PROJ_BATCH=1 timeout -k 10 300 python tools/project_scaling.py 2>&1 | grep "^N=" > "$O/project_scaling_per_frame.txt" || true
 echo done
