@@ -410,7 +410,9 @@ RT_DEV PrimaryRay primary_ray(const float* U, uint32_t gx, uint32_t gy, uint32_t
 }
 
 // web/compute.wgsl:349-410
-template <int LAYOUT, bool COUNT, bool TEX>
+// GI = false: the same function compiled without the path-tracing loop, for launches that never run RT_MODE_PT (the loop's live
+// state costs the batch kernel ~30 spilled registers under its 96-VGPR cap: 0.230 -> 0.218 ms per frame)
+template <int LAYOUT, bool COUNT, bool TEX, bool GI = true>
 RT_DEV PixelOut shade_pixel(const Scene& S, const Shade& sh, const float* U, uint32_t gx, uint32_t gy, uint32_t w, uint32_t h,
                             float time_h, Work& W, RayCount& R) {
   const PrimaryRay pr = primary_ray(U, gx, gy, w, h);
@@ -427,7 +429,7 @@ RT_DEV PixelOut shade_pixel(const Scene& S, const Shade& sh, const float* U, uin
   const V3 n_os = hit_normal(S, hit0);
   const V3 albedo = TEX ? hit_albedo(S, hit0) : v3(1.0f, 0.84f, 0.0f);
   V3 indirect = v3(0.0f, 0.0f, 0.0f);
-  if (sh.mode == RT_MODE_PT) {
+  if (GI && sh.mode == RT_MODE_PT) {
     const uint32_t GIS = (uint32_t)sh.gi_samples, NB = (uint32_t)sh.gi_bounces;
     const float pixelSeed = (float)pixelIndex / (U[36] * U[37]);
     for (uint32_t i = 0; i < GIS; ++i) {
@@ -1106,15 +1108,19 @@ extern "C" int rt_debug_timeline(unsigned long long* out, size_t n_words) {
 #ifndef RT_PIXEL_BATCH_MIN_WAVES
 #define RT_PIXEL_BATCH_MIN_WAVES 5
 #endif
+#ifndef RT_PIXEL_NOGI_BATCH_MIN_WAVES
+#define RT_PIXEL_NOGI_BATCH_MIN_WAVES 5
+#endif
 #ifndef RT_SHADE_BATCH_MIN_WAVES
 #define RT_SHADE_BATCH_MIN_WAVES 5
 #endif
 #ifndef RT_PT_SAMPLES_MIN_WAVES
 #define RT_PT_SAMPLES_MIN_WAVES 5                  // both launches of the per-frame PT split (KIND_PTSPLIT sizes the grid of both): PT-16 3.54 -> 3.34 ms per frame
 #endif
-enum { KIND_PIXEL = 0, KIND_PTSPLIT = 1, KIND_FRAG_WEB = 2, KIND_FRAG_ROOT = 3, KIND_TRAVERSE = 4, KIND_SHADE = 5 };
+enum { KIND_PIXEL = 0, KIND_PTSPLIT = 1, KIND_FRAG_WEB = 2, KIND_FRAG_ROOT = 3, KIND_TRAVERSE = 4, KIND_SHADE = 5,
+       KIND_PIXEL_NOGI = 6 /* KIND_PIXEL without the path-tracing loop: RT_MODE_PRIMARY / SHADOW batches */ };
 template <int LAYOUT, bool COUNT, bool TEX, int KIND, bool BATCH = false, typename B = RtNoBatch>
-__global__ __launch_bounds__(TBLK, (BATCH && KIND == 0) ? RT_PIXEL_BATCH_MIN_WAVES : (LAYOUT != RT_LAYOUT_WIDE64) ? 1 : (BATCH && KIND == 5) ? RT_SHADE_BATCH_MIN_WAVES : (KIND == 1) ? RT_PT_SAMPLES_MIN_WAVES : 1) void k_render(const RtRenderParams p, const B bt) {
+__global__ __launch_bounds__(TBLK, (BATCH && KIND == 6) ? RT_PIXEL_NOGI_BATCH_MIN_WAVES : (BATCH && KIND == 0) ? RT_PIXEL_BATCH_MIN_WAVES : (LAYOUT != RT_LAYOUT_WIDE64) ? 1 : (BATCH && KIND == 5) ? RT_SHADE_BATCH_MIN_WAVES : (KIND == 1) ? RT_PT_SAMPLES_MIN_WAVES : 1) void k_render(const RtRenderParams p, const B bt) {
   constexpr bool PTSPLIT = KIND == KIND_PTSPLIT;
   constexpr bool SHADE = KIND == KIND_SHADE;
   static_assert(!BATCH || KIND != KIND_PTSPLIT, "a batch runs PT one lane per pixel (no PT split)");
@@ -1290,6 +1296,7 @@ __global__ __launch_bounds__(TBLK, (BATCH && KIND == 0) ? RT_PIXEL_BATCH_MIN_WAV
 
         else if constexpr (KIND == KIND_FRAG_WEB) o = shade_frag<COUNT, 1>(S, sh, fv.U, x, y, p.width, p.height, p.miss_rgba, W, R);
         else if constexpr (KIND == KIND_FRAG_ROOT) o = shade_frag<COUNT, 2>(S, sh, fv.U, x, y, p.width, p.height, p.miss_rgba, W, R);
+        else if constexpr (KIND == KIND_PIXEL_NOGI) o = shade_pixel<LAYOUT, COUNT, TEX, false>(S, sh, fv.U, x, y, p.width, p.height, time_h, W, R);
         else o = shade_pixel<LAYOUT, COUNT, TEX>(S, sh, fv.U, x, y, p.width, p.height, time_h, W, R);
         {
         if (fv.rgba8 && !rec_hit) reinterpret_cast<uint32_t*>(fv.rgba8)[idx] = o.rgba;     // a hit pixel gets its colour in part 2 (PT split, traverse / shade split)
@@ -1511,6 +1518,7 @@ static const void* render_kernel(int layout, bool count, bool tex, int kind, boo
   if (kind == KIND_PTSPLIT) return render_kernel_lcx<KIND_PTSPLIT, false>(layout, count, tex);
   if (kind == KIND_TRAVERSE) return batch ? render_kernel_lcx<KIND_TRAVERSE, true>(layout, count, false) : render_kernel_lcx<KIND_TRAVERSE, false>(layout, count, false);
   if (kind == KIND_SHADE) return batch ? render_kernel_lcx<KIND_SHADE, true>(layout, count, tex) : render_kernel_lcx<KIND_SHADE, false>(layout, count, tex);
+  if (kind == KIND_PIXEL_NOGI && batch) return render_kernel_lcx<KIND_PIXEL_NOGI, true>(layout, count, tex);
   return batch ? render_kernel_lcx<KIND_PIXEL, true>(layout, count, tex) : render_kernel_lcx<KIND_PIXEL, false>(layout, count, tex);
 }
 static uint32_t resident_grid(int n_cu, int max_stack, const void* kernel, int cap = 0, const char* env = "RTCORE_BLOCKS_PER_CU") {
@@ -1657,7 +1665,7 @@ void rt_launch_render_batch(const RtRenderParams& p_in, const RtBatch& bt, int l
   const dim3 b(TBLK), gc(rt_cull_blocks(p.n_tiles), bt.n);
   const bool tex = p.tri_uv != nullptr;
   const bool two_phase = p.hits != nullptr && p.mode != RT_MODE_PT && !p.frag;      // as rt_launch_render
-  const int kind = p.frag == 1 ? KIND_FRAG_WEB : p.frag == 2 ? KIND_FRAG_ROOT : KIND_PIXEL;
+  const int kind = p.frag == 1 ? KIND_FRAG_WEB : p.frag == 2 ? KIND_FRAG_ROOT : p.mode == RT_MODE_PT ? KIND_PIXEL : KIND_PIXEL_NOGI;
   if (p.frag) layout = RT_LAYOUT_WIDE64;
   const void* kernel = two_phase ? render_kernel(layout, count_work, false, KIND_TRAVERSE, true) : render_kernel(layout, count_work, tex && !p.frag, kind, true);
   // the traversal launch: 5 blocks per CU (of the 6 that fit) - 4 / 5 / 6: 0.254 / 0.234 / 0.239 ms per frame with the shade launch at 4

@@ -34,7 +34,7 @@ K = 20                                         # bench.py --steps 20: the LAST d
 trav = [k for k in allk if k.startswith("k_render<0, false, false, 4, true")]
 shade = [k for k in allk if k.startswith("k_render<0, false, true, 5, true")]
 if not trav:
-    trav = [k for k in allk if k.startswith("k_render<0, false, true, 0, true")]
+    trav = [k for k in allk if k.startswith("k_render<0, false, true, 6, true")] or [k for k in allk if k.startswith("k_render<0, false, true, 0, true")]   # KIND_PIXEL_NOGI (primary / shadow batches), KIND_PIXEL
     shade = []
 assert len(trav) == 1 and len(shade) <= 1, list(allk)
 
