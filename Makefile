@@ -3,8 +3,11 @@
 #   make lib|oracle|host|clean
 HIPCC     ?= /opt/rocm/bin/hipcc
 ARCH      ?= gfx950
-# strict IEEE f32 on the device: no contraction, correctly rounded div/sqrt, denormals kept
-HIPFLAGS  ?= --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math \
+# strict IEEE f32 on the device: no contraction, correctly rounded div/sqrt, denormals kept.
+# -fno-slp-vectorize: the SLP vectoriser pairs f32 operations into v_pk_* and pays for it with v_mov shuffles and 4 - 9 more
+# live registers in the traversal kernels (same results bit for bit; cfg 3 batches 0.2445 -> 0.2256 ms per step, PT-16 2.54 -> 2.15:
+# profiles/r3/ab_slp_vectorize.txt)
+HIPFLAGS  ?= --offload-arch=$(ARCH) -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize \
              -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -Wall -Wno-unused-function $(EXTRA)
 CSRC      := raytracer_amd/csrc
 LIB       := raytracer_amd/lib/librtcore.so

@@ -93,7 +93,10 @@ RT_DEV Hit closest_wide(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Wor
   auto pop = [&]() -> uint32_t {
     while (sp > 0) {
       sp -= 1;
-      const uint2 e = S.stk[sp * TBLK];
+      // read as ONE 64-bit word: the compiler splits a uint2 load into the distance (in the loop) and the reference (behind it),
+      // two dependent LDS round trips per pop
+      const unsigned long long e64 = reinterpret_cast<const unsigned long long*>(S.stk)[sp * TBLK];
+      const uint2 e = make_uint2((uint32_t)e64, (uint32_t)(e64 >> 32));
       if (__uint_as_float(e.y) <= bestT) return e.x;  // re-test of compute.wgsl:275 with the stored entry distance
     }
     return REF_DONE;
