@@ -12,8 +12,5 @@ run() { tag=$1; lib=$2; shift 2
   if [ $lib = base ]; then unset RTCORE_LIBRARY; else export RTCORE_LIBRARY=$V/librtcore_$lib.so; fi
   timeout -k 10 200 python bench.py --no-cpu-baseline --no-legs "$@" > gpurun_out/ab_variants/$tag.json
   line $tag gpurun_out/ab_variants/$tag.json; }
-for v in sh1 sh2 sh4 sh1 sh2; do run shadow_$v $v --steps 20 --warmup 5; done
-for v in sh1 sh2 sh4; do run pt16_$v $v --mode pt --spp 16 --steps 10 --warmup 2; done
-for v in sh1 sh2; do run per_frame_$v $v --batch 1 --steps 20 --warmup 5; done
-export RTCORE_LIBRARY=$V/librtcore_sh2.so
-timeout -k 10 600 python -u -m pytest tests/test_gpu_render.py tests/test_gpu_batch.py tests/test_gpu_known_answers.py tests/test_gpu_texture.py -x -q --timeout 300 --timeout-method thread > gpurun_out/ab_variants/gpu_tests_sh2.log 2>&1; tail -3 gpurun_out/ab_variants/gpu_tests_sh2.log
+for v in base packed both base packed both; do run shadow_$v $v --steps 20 --warmup 5; done
+for v in base packed both; do run pt16_$v $v --mode pt --spp 16 --steps 10 --warmup 2; done
