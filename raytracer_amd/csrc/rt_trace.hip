@@ -31,18 +31,6 @@ constexpr int TBLK = 256;
 constexpr uint32_t REF_DONE = 0xFFFFFFFFu;
 constexpr float TWO_PI_F = 6.283185307179586f;
 
-// A value every active lane of the wave holds (derived from the frame's uniforms, a run's table entry, ...) moved to scalar
-// registers: the compiler cannot know that an LDS read or a load through a lane's pointer is wave-uniform, and vector registers
-// are this file's occupancy.
-RT_DEV uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-RT_DEV float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-RT_DEV V3 uni(V3 v) { return v3(uni(v.x), uni(v.y), uni(v.z)); }
-template <typename T>
-RT_DEV T* uni(T* q) {
-  const unsigned long long a = reinterpret_cast<unsigned long long>(q);
-  return reinterpret_cast<T*>(((unsigned long long)uni((uint32_t)(a >> 32)) << 32) | (unsigned long long)uni((uint32_t)a));
-}
-
 struct Work { uint32_t box, tri, hit, drops; };
 struct Hit { float t; uint32_t tri; float u, v; uint32_t steps; };   // steps: loop iterations of the traversal (scheduling hint only)
 
@@ -417,10 +405,10 @@ RT_DEV PrimaryRay primary_ray(const float* U, uint32_t gx, uint32_t gy, uint32_t
   r.uvx = uvx; r.uvy = fuy;
   r.pixelIndex = sat_u32(py) * w + sat_u32(px);
   const float* model = U + 20;
-  r.ro = uni(mat_mul4(model, ro_w.x, ro_w.y, ro_w.z, 1.0f));     // functions of the frame's uniforms alone, and a wave works on ONE frame
+  r.ro = mat_mul4(model, ro_w.x, ro_w.y, ro_w.z, 1.0f);
   r.rd = normalize3(mat_mul3(model, rd_w));
   r.inv = rcp3(r.rd);
-  r.light = uni(mat_mul4(model, U[4], U[5], U[6], U[7]));
+  r.light = mat_mul4(model, U[4], U[5], U[6], U[7]);
   return r;
 }
 
@@ -1249,11 +1237,10 @@ __global__ __launch_bounds__(TBLK, (BATCH && KIND == 6) ? RT_PIXEL_NOGI_BATCH_MI
           if (m) o = r * 64 + 63 - __clzll((long long)m);
         }
         o = __builtin_amdgcn_readfirstlane(o);
-        const uint32_t f = uni(seg_frame_p[o]), first = uni(seg_first_p[o]), start = uni(seg_start_p[o]), cnt = uni(seg_count_p[o]);
+        const uint32_t f = seg_frame_p[o], first = seg_first_p[o], start = seg_start_p[o], cnt = seg_count_p[o];
         fv = frame_view<true>(p, bt, f);
-        fv.U = uni(fv.U); fv.rgba8 = uni(fv.rgba8); fv.hit_tri = uni(fv.hit_tri); fv.hit_t = uni(fv.hit_t); fv.list = uni(fv.list); fv.hits = uni(fv.hits);
         li = start + (chunk - first) * ITEM + (uint32_t)lane; li_end = start + cnt;
-        time_h = uni((float)hash_u32(sat_u32(fv.U[38])));
+        time_h = (float)hash_u32(sat_u32(fv.U[38]));
         last_frame = f + 1u == bt.n;
         batch_frame = f;
       }

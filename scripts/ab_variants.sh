@@ -12,8 +12,5 @@ run() { tag=$1; lib=$2; shift 2
   if [ $lib = base ]; then unset RTCORE_LIBRARY; else export RTCORE_LIBRARY=$V/librtcore_$lib.so; fi
   timeout -k 10 200 python bench.py --no-cpu-baseline --no-legs "$@" > gpurun_out/ab_variants/$tag.json
   line $tag gpurun_out/ab_variants/$tag.json; }
-for v in old base uni_nogi6 old base uni_nogi6; do run shadow_$v $v --steps 20 --warmup 5; done
-for v in old base uni_pt4 uni_pt6; do run pt16_$v $v --mode pt --spp 16 --steps 10 --warmup 2; done
-for v in old base; do run fragweb_$v $v --mode frag-web --steps 5 --warmup 1; run per_frame_$v $v --batch 1 --steps 20 --warmup 5; run s70k_$v $v --scene s70k --width 1920 --height 1080 --mode primary --steps 32 --warmup 32; done
-unset RTCORE_LIBRARY
-timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/ab_variants/gpu_tests.log 2>&1; tail -3 gpurun_out/ab_variants/gpu_tests.log
+for v in base packed both base packed both; do run shadow_$v $v --steps 20 --warmup 5; done
+for v in base packed both; do run pt16_$v $v --mode pt --spp 16 --steps 10 --warmup 2; done
