@@ -1137,7 +1137,7 @@ __global__ __launch_bounds__(TBLK, (BATCH && KIND == 6) ? RT_PIXEL_NOGI_BATCH_MI
   extern __shared__ __align__(16) unsigned char smem[];
 #ifdef RT_TIMELINE
   const unsigned long long tl_start = wall_clock64();
-  unsigned long long tl_last = tl_start, tl_chunks = 0;
+  unsigned long long tl_last = tl_start, tl_chunks = 0, tl_max = 0;   // tl_max: the wave's longest chunk (10 ns ticks)
 #endif
   uint2* stk = reinterpret_cast<uint2*>(smem);
 
@@ -1220,7 +1220,7 @@ __global__ __launch_bounds__(TBLK, (BATCH && KIND == 6) ? RT_PIXEL_NOGI_BATCH_MI
       const uint32_t chunk = shard_chunk((uint32_t)shard, (uint32_t)__builtin_amdgcn_readfirstlane((int)h), p.shard_group);
       if (chunk >= n_chunks) break;
 #ifdef RT_TIMELINE
-      tl_last = wall_clock64(); tl_chunks += 1;
+      { const unsigned long long now = wall_clock64(); if (tl_chunks && now - tl_last > tl_max) tl_max = now - tl_last; tl_last = now; tl_chunks += 1; }
 #endif
       // this chunk's frame and its entries of that frame's list
       FrameView fv = frame_view<false>(p, bt, 0u);
@@ -1335,7 +1335,9 @@ __global__ __launch_bounds__(TBLK, (BATCH && KIND == 6) ? RT_PIXEL_NOGI_BATCH_MI
 #ifdef RT_TIMELINE
   if (lane == 0 && blockIdx.x < 4096) {
     unsigned long long* t = g_timeline[blockIdx.x * 4 + (threadIdx.x >> 6)];
-    t[0] = tl_start; t[1] = tl_last; t[2] = wall_clock64(); t[3] = tl_chunks;
+    const unsigned long long tl_end = wall_clock64();
+    if (tl_chunks && tl_end - tl_last > tl_max) tl_max = tl_end - tl_last;
+    t[0] = tl_start; t[1] = tl_last; t[2] = tl_end; t[3] = tl_chunks | (tl_max << 32);
   }
 #endif
   if constexpr (!BATCH) flush_stats<COUNT>(p, lane, R, W, pixels);

@@ -33,9 +33,10 @@ assert rc == 0
 b = buf[buf[:, 2] > 0].astype(np.int64)
 t0 = b[:, 0].min()
 tick = 1e-2   # wall_clock64 runs at 100 MHz: 10 ns per tick -> us
-start, last, end, n = (b[:, 0] - t0) * tick, (b[:, 1] - t0) * tick, (b[:, 2] - t0) * tick, b[:, 3]
+start, last, end, n = (b[:, 0] - t0) * tick, (b[:, 1] - t0) * tick, (b[:, 2] - t0) * tick, b[:, 3] & 0xFFFFFFFF
+longest = (b[:, 3] >> 32) * tick            # the wave's longest chunk
 print(f"waves {len(b)}  kernel_ms(events) {st['ms_traverse']:.3f}  span {end.max():.1f} us")
-for name, v in (("start", start), ("last chunk start", last), ("end", end), ("last chunk duration", end - last), ("chunks/wave", n.astype(float))):
+for name, v in (("start", start), ("last chunk start", last), ("end", end), ("last chunk duration", end - last), ("longest chunk", longest), ("chunks/wave", n.astype(float))):
     q = np.percentile(v, [0, 10, 50, 90, 99, 100])
     print(f"{name:22s} min {q[0]:8.1f}  p10 {q[1]:8.1f}  p50 {q[2]:8.1f}  p90 {q[3]:8.1f}  p99 {q[4]:8.1f}  max {q[5]:8.1f}")
 # how many waves are still running at time t
