@@ -1616,8 +1616,11 @@ void rt_launch_render(const RtRenderParams& p_in, int layout, bool count_work, b
   const bool two_phase = p.hits != nullptr && kind == KIND_PIXEL && p.mode != RT_MODE_PT;
   const void* kernel = two_phase ? render_kernel(layout, count_work, false, KIND_TRAVERSE, false) : render_kernel(layout, count_work, tex && !p.frag, kind, false);
   // one frame per launch: more resident waves stretch the tail (every chain of dependent fetches gets slower) and lose what
-  // they hide; 3 blocks per CU stay the default there (profiles/r3/ab_two_phase.txt), a batch takes all that fit
-  p.render_blocks = resident_grid(n_cu, p.max_stack, kernel, two_phase ? 3 : 0, two_phase ? "RTCORE_TRAVERSE_BPC" : "RTCORE_BLOCKS_PER_CU");
+  // they hide; 3 blocks per CU stay the default there (profiles/r3/ab_two_phase.txt), a batch takes all that fit.  (Built without
+  // the SLP vectoriser the untextured whole-pixel kernel fits 4: cfg 3 untextured, one frame per pipeline, 2 / 3 / 4 blocks per CU
+  // = 0.506 / 0.485 / 0.510 ms, primary only 0.482 / 0.466 / 0.504; the PT split's launches do best with all that fit.)
+  const int one_frame_cap = (two_phase || kind == KIND_PIXEL) ? 3 : 0;
+  p.render_blocks = resident_grid(n_cu, p.max_stack, kernel, one_frame_cap, two_phase ? "RTCORE_TRAVERSE_BPC" : "RTCORE_BLOCKS_PER_CU");
   // A persistent grid that fills the chip leaves a frame queued behind it nothing but its tail to overlap with.  Frames
   // in flight therefore take 2 of the (usually 3) resident blocks per CU each, so that two of them really run side by
   // side (cfg 3, two in flight: 0.440 -> 0.400 ms per frame; a 1/8 stripe share, three in flight: 0.146 -> 0.125 ms).
