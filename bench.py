@@ -251,7 +251,11 @@ def main():
         bframes.finish()
     # warm-up: W steps - in whole pipelines of the timed loop's shape when frames are batched, so that every launch of the traversal
     # kernel in a run has the timed launches' size (rocprofv3's per-kernel average is then the average of like launches)
+    # (profiled, so that the ring of hipEvents rt_profile_begin creates on first use exists before the clock starts: 1280
+    # hipEventCreate calls cost the first timed pipeline 0.15 ms)
+    ctx.profile_begin()
     run_frames(views, args.warmup if bframes is None else -(-args.warmup // K) * K)
+    ctx.profile_end_phases()
 
     def fence():
         frame.finish()
