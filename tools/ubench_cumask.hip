@@ -1,5 +1,7 @@
 // ubench_cumask.hip - does hipExtStreamCreateWithCUMask confine a launch to the CUs of its mask on this box?  Prints the return
 // codes and, per launch, the set of (XCC, SE, CU) ids its blocks ran on.
+// Observed (ROCm 7.2.0 image, MI355X, round 3): the process dies with a segmentation fault INSIDE hipExtStreamCreateWithCUMask,
+// before anything is launched (profiles/r3/ab_express_lanes.txt) - so nothing in the library uses CU masks.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
