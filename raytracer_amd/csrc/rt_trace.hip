@@ -903,12 +903,8 @@ __global__ __launch_bounds__(TBLK) void k_cull(const RtRenderParams p, const B b
         else for (uint32_t j = 0; j < nv; ++j) d[j] = 1e20f;
       }
     }
-    if (!fv.dup)
-      for (int c = w; c < N_CLASS; c += TBLK / 64) {             // as below: empty masks, empty totals
-        const uint32_t tile = blockIdx.x * CULL_TPB + (uint32_t)lane;
-        if (tile < p.n_tiles) fv.masks[(size_t)tile * N_CLASS + c] = 0ull;
-        if (lane == 0) fv.block_total[(size_t)blockIdx.x * N_CLASS + c] = 0u;
-      }
+    // empty totals; the tiles' masks are not written: k_compact sees from the totals that the block lists nothing and never reads them
+    if (!fv.dup && threadIdx.x < N_CLASS) fv.block_total[(size_t)blockIdx.x * N_CLASS + threadIdx.x] = 0u;
     return;
   }
   uint8_t* sm8 = reinterpret_cast<uint8_t*>(&s_m[0][0]);
@@ -1050,12 +1046,22 @@ __global__ __launch_bounds__(TBLK) void k_compact(const RtRenderParams p, const 
   const uint32_t me = blockIdx.x;
   constexpr int CPW = (N_CLASS + TBLK / 64 - 1) / (TBLK / 64);     // classes per wave: wave w scans classes w, w + 4
   unsigned long long my_mask[CPW];
+  // A block that lists nothing (most of a frame: k_cull's blocks outside the root box's rectangle, which do not even write masks):
+  // k_scan's exclusive prefixes say so - this block's share of class c is the next block's prefix minus its own.
+  bool empty = true;
+#pragma unroll
+  for (int c = 0; c < N_CLASS; ++c) {
+    const uint32_t a = fv.block_total[(size_t)me * N_CLASS + c];
+    const uint32_t b = (me + 1u < gridDim.x) ? fv.block_total[(size_t)(me + 1u) * N_CLASS + c] : fv.list_count[16 + c];
+    empty = empty && a == b;
+  }
+  if (empty && me != 0u) return;                                 // (block-uniform; block 0 still derives the frame's thresholds below)
   {
     const uint32_t tile = me * CULL_TPB + (uint32_t)lane;
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
       const int c = w + i * (TBLK / 64);
-      my_mask[i] = (c < N_CLASS && tile < p.n_tiles) ? fv.masks[(size_t)tile * N_CLASS + c] : 0ull;
+      my_mask[i] = (!empty && c < N_CLASS && tile < p.n_tiles) ? fv.masks[(size_t)tile * N_CLASS + c] : 0ull;
     }
     if (w == TBLK / 64 - 1) s_txy[lane] = (tile % p.tiles_x) | ((tile / p.tiles_x) << 16);   // tile coordinates, once per tile
   }
