@@ -879,6 +879,15 @@ int fill_scene_params(rt_ctx* ctx, const rt_render_opts* opts, RtRenderParams& p
   if (ctx->have_paired) { const char* e = getenv("RTCORE_WIDE_PAIRED"); if (e && e[0] == '1') p.wide = ctx->wide_paired.p; }
   p.tri_pre = ctx->bvh.tri_pre; p.root_ref = ctx->bvh.root_ref; p.leaf_shift = ctx->bvh.leaf_shift;
   p.nodes_v2 = ctx->bvh.v2 ? 1 : 0;
+  {   // (RTCORE_FAR_ADDRESSES=1: the 64-bit form everywhere - tests, A/B)
+    const char* w = reinterpret_cast<const char*>(p.wide); const char* q = reinterpret_cast<const char*>(p.tri_pre);
+    const char* lo = w < q ? w : q;
+    const char* w_end = w + 64ull * ctx->bvh.n_nodes; const char* q_end = q + 48ull * ctx->bvh.n_tri;
+    const char* hi = w_end > q_end ? w_end : q_end;
+    const char* far = getenv("RTCORE_FAR_ADDRESSES");
+    p.near32 = (w && q && (unsigned long long)(hi - lo) < 0xFFFFFF00ull && !(far && far[0] == '1')) ? 1u : 0u;
+    p.near_base = lo; p.near_wide_off = (uint32_t)(w - lo); p.near_pre_off = (uint32_t)(q - lo);
+  }
   // one budget step per loop iteration of the walk: WIDE64 spends one per internal record AND one per leaf triangle
   // (closest_wide advances leaf_j one triangle per iteration), AOS32 one per node visit with twice this budget
   p.step_budget = ctx->bvh.n_nodes + ctx->bvh.n_tri + 64u;

@@ -39,6 +39,9 @@ struct RtBvhDev {
 // Surface extension (include/rtcore.h "material / texture shading")
 struct RtTexDev { const uint32_t* texels; uint32_t w, h; };   // texel = R | G<<8 | B<<16 | 255<<24, row 0 = top
 
+// internal third value of the LAYOUT template parameter: RT_LAYOUT_WIDE64 records addressed with 32-bit offsets (RtRenderParams::near32)
+#define RT_LAYOUT_WIDE64_NEAR 2
+
 struct RtRenderParams {
   const float4*   tri_uv;          // [2T] {u0 v0 u1 v1} {u2 v2 bits(material) 0}, BVH order; NULL unless RT_FLAG_TEXTURED
   const float4*   materials;       // [n_materials] {Kd.rgb, bits(texture slot)}
@@ -49,6 +52,10 @@ struct RtRenderParams {
   const float*  tri_nor;
   const float4* wide;
   const float4* tri_pre;
+  // (kernels: template LAYOUT = RT_LAYOUT_WIDE64_NEAR)
+  // both traversal tables inside ONE 4 GB window (near32 != 0): records are then addressed as near_base + a 32-bit byte offset,
+  // which the vector memory instructions take as scalar base + 32-bit lane offset; else 64-bit pointer arithmetic per fetch
+  const char* near_base; uint32_t near_wide_off, near_pre_off, near32;
   uint32_t root_ref;
   int      leaf_shift;
   int      nodes_v2;               // encoding of `nodes` (read by the AOS32 walk only)

@@ -45,6 +45,7 @@ struct Scene {
   bool v2;                 // encoding of `nodes`
   int max_stack;
   uint32_t step_budget;    // > number of nodes: a valid tree never exhausts it; a cyclic (corrupt) import cannot hang the GPU
+  const char* base; uint32_t wide_off, pre_off;   // RtRenderParams::near_*: 32-bit record offsets from one scalar base (NEAR kernels)
   uint2* stk;              // this thread's LDS column, stride TBLK: {reference, bits(entry distance)} - one 8-byte read per pop
   const float4* tri_uv;    // surface extension (rtcore.h "material / texture shading")
   const float4* materials;
@@ -78,7 +79,11 @@ RT_DEV bool moller_trumbore(V3 ro, V3 rd, V3 v0, V3 e1, V3 e2, float& t, float& 
 }
 
 // ---------------------------------------------------------------- WIDE64 traversal
-template <bool COUNT, int TRI = 0>
+// NEAR: both tables lie in one 4 GB window (RtRenderParams::near32): a record's address is scalar base + 32-bit byte offset, which
+// the vector memory instructions take directly (global_load ... v_off, s[base]) - 8 full-rate address instructions per step instead
+// of v_lshlrev_b64 / v_lshl_add_u64 / v_mad_u64_u32 behind exec-mask branches (-1.9 % of the shadow batch kernel).  A compile-time
+// switch: with a run-time one the compiler merges the two forms' loads behind a pointer phi and both lose.
+template <bool COUNT, int TRI = 0, bool NEAR = false>
 RT_DEV Hit closest_wide(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Work& W) {
   float bestT = maxDist, bu = 0.0f, bv = 0.0f;
   uint32_t bestTri = 0xFFFFFFFFu;
@@ -113,10 +118,16 @@ RT_DEV Hit closest_wide(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Wor
     const uint32_t start = (S.leaf_shift >= 31) ? body : (body & ((1u << S.leaf_shift) - 1u));
     const uint32_t count = (S.leaf_shift >= 31) ? 1u : ((body >> S.leaf_shift) + 1u);
     const uint32_t ti = start + leaf_j;
-    const float4* ptr = is_leaf ? (S.tri_pre + 3 * (size_t)ti) : (S.wide + 4 * (size_t)cur);
+    uint32_t off32 = 0;
+    const float4* ptr;
+    if constexpr (NEAR) {
+      uint32_t ti3; asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(ti3) : "v"(ti));       // 3 * ti (48 * ti would become a v_mad_u64_u32)
+      off32 = is_leaf ? (S.pre_off + (ti3 << 4)) : (S.wide_off + (cur << 6));
+      ptr = reinterpret_cast<const float4*>(S.base + off32);
+    } else ptr = is_leaf ? (S.tri_pre + 3 * (size_t)ti) : (S.wide + 4 * (size_t)cur);
     const float4 a = ptr[0], b = ptr[1], c = ptr[2];
     if (!is_leaf) {                                      // internal: both children from one 64 B record
-      const float4 d = ptr[3];
+      const float4 d = NEAR ? *reinterpret_cast<const float4*>(S.base + (off32 + 48u)) : ptr[3];
       float t0n, t0f, t1n, t1f;
       slab(ro, inv, xyz(a), xyz(b), t0n, t0f);
       slab(ro, inv, xyz(c), xyz(d), t1n, t1f);
@@ -148,7 +159,7 @@ RT_DEV Hit closest_wide(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Wor
   return h;
 }
 
-template <bool COUNT, int TRI = 0>
+template <bool COUNT, int TRI = 0, bool NEAR = false>
 RT_DEV bool occluded_wide(const Scene& S, V3 ro, V3 rd, float maxDist, Work& W) {
   const V3 inv = rcp3(rd);
   {
@@ -161,7 +172,7 @@ RT_DEV bool occluded_wide(const Scene& S, V3 ro, V3 rd, float maxDist, Work& W) 
   uint32_t budget = S.step_budget;
   while ((int)cur >= 0) {                              // child0 chain only (compute.wgsl:187)
     if (--budget == 0) return false;
-    const float4* n = S.wide + 4 * (size_t)cur;
+    const float4* n = NEAR ? reinterpret_cast<const float4*>(S.base + (uint32_t)(S.wide_off + (cur << 6))) : S.wide + 4 * (size_t)cur;
     const float4 a = n[0], b = n[1];
     float tn, tf; slab(ro, inv, xyz(a), xyz(b), tn, tf);
     if (COUNT) W.box += 1;
@@ -273,12 +284,12 @@ RT_DEV bool occluded_aos(const Scene& S, V3 ro, V3 rd, float maxDist, Work& W) {
 
 template <int LAYOUT, bool COUNT, int TRI = 0>
 RT_DEV Hit closest(const Scene& S, V3 ro, V3 rd, V3 inv, float maxDist, Work& W) {
-  if constexpr (LAYOUT == RT_LAYOUT_WIDE64) return closest_wide<COUNT, TRI>(S, ro, rd, inv, maxDist, W);
+  if constexpr (LAYOUT != RT_LAYOUT_AOS32) return closest_wide<COUNT, TRI, LAYOUT == RT_LAYOUT_WIDE64_NEAR>(S, ro, rd, inv, maxDist, W);
   else return closest_aos<COUNT, TRI>(S, ro, rd, inv, maxDist, W);
 }
 template <int LAYOUT, bool COUNT, int TRI = 0>
 RT_DEV bool occluded(const Scene& S, V3 ro, V3 rd, float maxDist, Work& W) {
-  if constexpr (LAYOUT == RT_LAYOUT_WIDE64) return occluded_wide<COUNT, TRI>(S, ro, rd, maxDist, W);
+  if constexpr (LAYOUT != RT_LAYOUT_AOS32) return occluded_wide<COUNT, TRI, LAYOUT == RT_LAYOUT_WIDE64_NEAR>(S, ro, rd, maxDist, W);
   else return occluded_aos<COUNT, TRI>(S, ro, rd, maxDist, W);
 }
 
@@ -476,7 +487,7 @@ RT_DEV uint32_t shade_known_hit(const Scene& S, const Shade& sh, const float* U,
                                 uint32_t tri, float time_h, Work& W, RayCount& R) {
   const PrimaryRay pr = primary_ray(U, gx, gy, w, h);
   Hit hit0; hit0.tri = tri; hit0.steps = 0;
-  if constexpr (LAYOUT == RT_LAYOUT_WIDE64) {
+  if constexpr (LAYOUT != RT_LAYOUT_AOS32) {
     const float4 q0 = S.tri_pre[3 * (size_t)tri + 0], q1 = S.tri_pre[3 * (size_t)tri + 1], q2 = S.tri_pre[3 * (size_t)tri + 2];
     (void)moller_trumbore<0>(pr.ro, pr.rd, xyz(q0), xyz(q1), xyz(q2), hit0.t, hit0.u, hit0.v);
   } else {
@@ -1171,7 +1182,7 @@ extern "C" int rt_debug_timeline(unsigned long long* out, size_t n_words) {
 enum { KIND_PIXEL = 0, KIND_PTSPLIT = 1, KIND_FRAG_WEB = 2, KIND_FRAG_ROOT = 3, KIND_TRAVERSE = 4, KIND_SHADE = 5,
        KIND_PIXEL_NOGI = 6 /* KIND_PIXEL without the path-tracing loop: RT_MODE_PRIMARY / SHADOW batches */ };
 template <int LAYOUT, bool COUNT, bool TEX, int KIND, bool BATCH = false, typename B = RtNoBatch>
-__global__ __launch_bounds__(TBLK, (BATCH && KIND == 6) ? RT_PIXEL_NOGI_BATCH_MIN_WAVES : (BATCH && KIND == 0) ? RT_PIXEL_BATCH_MIN_WAVES : (LAYOUT != RT_LAYOUT_WIDE64) ? 1 : (BATCH && KIND == 5) ? RT_SHADE_BATCH_MIN_WAVES : (KIND == 1) ? RT_PT_SAMPLES_MIN_WAVES : 1) void k_render(const RtRenderParams p, const B bt) {
+__global__ __launch_bounds__(TBLK, (BATCH && KIND == 6) ? RT_PIXEL_NOGI_BATCH_MIN_WAVES : (BATCH && KIND == 0) ? RT_PIXEL_BATCH_MIN_WAVES : (LAYOUT == RT_LAYOUT_AOS32) ? 1 : (BATCH && KIND == 5) ? RT_SHADE_BATCH_MIN_WAVES : (KIND == 1) ? RT_PT_SAMPLES_MIN_WAVES : 1) void k_render(const RtRenderParams p, const B bt) {
   constexpr bool PTSPLIT = KIND == KIND_PTSPLIT;
   constexpr bool SHADE = KIND == KIND_SHADE;
   static_assert(!BATCH || KIND != KIND_PTSPLIT, "a batch runs PT one lane per pixel (no PT split)");
@@ -1194,6 +1205,7 @@ __global__ __launch_bounds__(TBLK, (BATCH && KIND == 6) ? RT_PIXEL_NOGI_BATCH_MI
   S.tri_pos = reinterpret_cast<const float4*>(p.tri_pos);
   S.tri_nor = reinterpret_cast<const float4*>(p.tri_nor);
   S.wide = p.wide; S.tri_pre = p.tri_pre;
+  S.base = p.near_base; S.wide_off = p.near_wide_off; S.pre_off = p.near_pre_off;
   S.root_ref = p.root_ref; S.leaf_shift = p.leaf_shift; S.v2 = p.nodes_v2 != 0; S.max_stack = p.max_stack; S.step_budget = p.step_budget;
   S.stk = stk + threadIdx.x;
   S.tri_uv = p.tri_uv; S.materials = p.materials; S.textures = p.textures; S.n_materials = p.n_materials; S.n_textures = p.n_textures;
@@ -1409,6 +1421,7 @@ __global__ __launch_bounds__(TBLK, LAYOUT == RT_LAYOUT_WIDE64 ? RT_PT_SAMPLES_MI
   S.tri_pos = reinterpret_cast<const float4*>(p.tri_pos);
   S.tri_nor = reinterpret_cast<const float4*>(p.tri_nor);
   S.wide = p.wide; S.tri_pre = p.tri_pre;
+  S.base = p.near_base; S.wide_off = p.near_wide_off; S.pre_off = p.near_pre_off;
   S.root_ref = p.root_ref; S.leaf_shift = p.leaf_shift; S.v2 = p.nodes_v2 != 0; S.max_stack = p.max_stack; S.step_budget = p.step_budget;
   S.stk = stk + threadIdx.x;
   S.tri_uv = p.tri_uv; S.materials = p.materials; S.textures = p.textures; S.n_materials = p.n_materials; S.n_textures = p.n_textures;
@@ -1555,7 +1568,9 @@ static const void* render_kernel_ptr() {
 }
 template <int K, bool BT>
 static const void* render_kernel_lcx(int layout, bool count, bool tex) {
-  if (layout == RT_LAYOUT_WIDE64) {
+  // (counting launches are not timed: they keep the 64-bit form, one instantiation less each)
+  if (layout == RT_LAYOUT_WIDE64_NEAR && !count) return tex ? render_kernel_ptr<RT_LAYOUT_WIDE64_NEAR, false, true, K, BT>() : render_kernel_ptr<RT_LAYOUT_WIDE64_NEAR, false, false, K, BT>();
+  if (layout != RT_LAYOUT_AOS32) {
     if (count) return tex ? render_kernel_ptr<RT_LAYOUT_WIDE64, true, true, K, BT>() : render_kernel_ptr<RT_LAYOUT_WIDE64, true, false, K, BT>();
     return tex ? render_kernel_ptr<RT_LAYOUT_WIDE64, false, true, K, BT>() : render_kernel_ptr<RT_LAYOUT_WIDE64, false, false, K, BT>();
   }
@@ -1662,7 +1677,8 @@ void rt_launch_render(const RtRenderParams& p_in, int layout, bool count_work, b
   if (p.frag) layout = RT_LAYOUT_WIDE64;
   // RT_MODE_PRIMARY / SHADOW with a hit buffer: two launches, the primary rays' walk and the colour of the hits
   const bool two_phase = p.hits != nullptr && kind == KIND_PIXEL && p.mode != RT_MODE_PT;
-  const void* kernel = two_phase ? render_kernel(layout, count_work, false, KIND_TRAVERSE, false) : render_kernel(layout, count_work, tex && !p.frag, kind, false);
+  const int klayout = (layout == RT_LAYOUT_WIDE64 && p.near32 && !p.frag) ? RT_LAYOUT_WIDE64_NEAR : layout;   // k_render's instantiation; k_pt_samples keeps `layout`
+  const void* kernel = two_phase ? render_kernel(klayout, count_work, false, KIND_TRAVERSE, false) : render_kernel(klayout, count_work, tex && !p.frag, kind, false);
   // one frame per launch: more resident waves stretch the tail (every chain of dependent fetches gets slower) and lose what
   // they hide; 3 blocks per CU stay the default there (profiles/r3/ab_two_phase.txt), a batch takes all that fit.  (Built without
   // the SLP vectoriser the untextured whole-pixel kernel fits 4: cfg 3 untextured, one frame per pipeline, 2 / 3 / 4 blocks per CU
@@ -1685,7 +1701,7 @@ void rt_launch_render(const RtRenderParams& p_in, int layout, bool count_work, b
   if (ev_mid) (void)hipEventRecord(ev_mid, s);          // behind the first traversal launch (the only one unless the frame is split)
   uint32_t stat_blocks = split ? 2u * g.x : g.x;
   if (two_phase) {
-    const void* shade = render_kernel(layout, count_work, tex, KIND_SHADE, false);
+    const void* shade = render_kernel(klayout, count_work, tex, KIND_SHADE, false);
     RtRenderParams p2 = p;
     p2.render_blocks = resident_grid(n_cu, 0, shade, 4, "RTCORE_SHADE_BPC");
     p2.stats_partial = p.stats_partial + (size_t)g.x * 8;
@@ -1723,7 +1739,8 @@ void rt_launch_render_batch(const RtRenderParams& p_in, const RtBatch& bt, int l
   const bool two_phase = p.hits != nullptr && p.mode != RT_MODE_PT && !p.frag;      // as rt_launch_render
   const int kind = p.frag == 1 ? KIND_FRAG_WEB : p.frag == 2 ? KIND_FRAG_ROOT : p.mode == RT_MODE_PT ? KIND_PIXEL : KIND_PIXEL_NOGI;
   if (p.frag) layout = RT_LAYOUT_WIDE64;
-  const void* kernel = two_phase ? render_kernel(layout, count_work, false, KIND_TRAVERSE, true) : render_kernel(layout, count_work, tex && !p.frag, kind, true);
+  const int klayout = (layout == RT_LAYOUT_WIDE64 && p.near32 && !p.frag) ? RT_LAYOUT_WIDE64_NEAR : layout;
+  const void* kernel = two_phase ? render_kernel(klayout, count_work, false, KIND_TRAVERSE, true) : render_kernel(klayout, count_work, tex && !p.frag, kind, true);
   // the traversal launch: 5 blocks per CU (of the 6 that fit) - 4 / 5 / 6: 0.254 / 0.234 / 0.239 ms per frame with the shade launch at 4
   p.render_blocks = resident_grid(n_cu, p.max_stack, kernel, two_phase ? 5 : 0, two_phase ? "RTCORE_TRAVERSE_BPC" : "RTCORE_BLOCKS_PER_CU");
   if (p.blocks_per_cu_cap && !getenv("RTCORE_BLOCKS_PER_CU")) p.render_blocks = std::min(p.render_blocks, (uint32_t)n_cu * p.blocks_per_cu_cap);   // pipelines in flight share the CUs
@@ -1736,7 +1753,7 @@ void rt_launch_render_batch(const RtRenderParams& p_in, const RtBatch& bt, int l
   RtRenderParams p2 = p;
   const void* shade = nullptr;
   if (two_phase) {
-    shade = render_kernel(layout, count_work, tex, KIND_SHADE, true);
+    shade = render_kernel(klayout, count_work, tex, KIND_SHADE, true);
     p2.render_blocks = resident_grid(n_cu, 0, shade, 5, "RTCORE_SHADE_BPC");
     if (p.blocks_per_cu_cap && !getenv("RTCORE_SHADE_BPC")) p2.render_blocks = std::min(p2.render_blocks, (uint32_t)n_cu * p.blocks_per_cu_cap);
     slots_b = p2.render_blocks * (TBLK / 64);

@@ -257,3 +257,31 @@ def test_batch_counters_equal_the_oracle_per_frame(rt, oracle):
             assert st[f]["pixels"] == rows * w
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_near_and_far_record_addresses_are_the_same_frames(rt, monkeypatch):
+    """The traversal kernels address their records as scalar base + 32-bit offset while both tables lie in one 4 GB window
+    (LAYOUT = RT_LAYOUT_WIDE64_NEAR) and by 64-bit pointer arithmetic otherwise (cfg 5's tables: tests/test_gpu_cfg5_full.py).
+    RTCORE_FAR_ADDRESSES=1 selects the 64-bit form on a small scene: same images, hit ids, distances - batches and single frames,
+    shadow and PT."""
+    import torch
+    from raytracer_amd import scenes
+    mesh = rt.normalize_mesh(scenes.s70k())
+    ctx = rt.Context(0)
+    try:
+        ctx.set_mesh(mesh)
+        ctx.build_lbvh()
+        Us = _views(rt, 483, 271, 4)
+        for opts in (rt.render_opts(mode=rt.MODE_SHADOW), rt.render_opts(mode=rt.MODE_PT, gi_samples=2, gi_bounces=2)):
+            monkeypatch.setenv("RTCORE_FAR_ADDRESSES", "0")
+            near = _batch(ctx, torch, Us, opts)
+            near_one = _single(ctx, torch, Us, opts)
+            monkeypatch.setenv("RTCORE_FAR_ADDRESSES", "1")
+            far = _batch(ctx, torch, Us, opts)
+            far_one = _single(ctx, torch, Us, opts)
+            _same(far, near, f"far vs near addresses, batch, mode {opts.mode}")
+            _same(far_one, near_one, f"far vs near addresses, single frames, mode {opts.mode}")
+            _same(near, near_one, f"batch vs single frames, mode {opts.mode}")
+    finally:
+        monkeypatch.delenv("RTCORE_FAR_ADDRESSES", raising=False)
