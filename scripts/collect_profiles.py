@@ -31,10 +31,11 @@ allk = json.load(open(os.path.join(src, "traffic_all.json")))
 K = 20                                         # bench.py --steps 20: the LAST dispatch of the batch kernels in every pass is the timed pipeline of 20 frames
 # the batch pipeline's traversal kernel: the whole-pixel kernel (WIDE64, no counters, textured, KIND_PIXEL, batch) - or, with
 # RTCORE_TWO_PHASE=1, KIND_TRAVERSE + KIND_SHADE
-trav = [k for k in allk if k.startswith("k_render<0, false, false, 4, true")]
-shade = [k for k in allk if k.startswith("k_render<0, false, true, 5, true")]
+trav = [k for k in allk if k.startswith(("k_render<2, false, false, 4, true", "k_render<0, false, false, 4, true"))]   # (LAYOUT 2 = WIDE64 records behind 32-bit offsets)
+shade = [k for k in allk if k.startswith(("k_render<2, false, true, 5, true", "k_render<0, false, true, 5, true"))]
 if not trav:
-    trav = [k for k in allk if k.startswith("k_render<0, false, true, 6, true")] or [k for k in allk if k.startswith("k_render<0, false, true, 0, true")]   # KIND_PIXEL_NOGI (primary / shadow batches), KIND_PIXEL
+    trav = ([k for k in allk if k.startswith("k_render<2, false, true, 6, true")] or [k for k in allk if k.startswith("k_render<0, false, true, 6, true")]
+            or [k for k in allk if k.startswith("k_render<0, false, true, 0, true")])   # KIND_PIXEL_NOGI (primary / shadow batches), KIND_PIXEL
     shade = []
 assert len(trav) == 1 and len(shade) <= 1, list(allk)
 
