@@ -167,6 +167,26 @@ def test_cull_rectangle_is_conservative(gpu_ctx, oracle, rt, plane_mesh):
     assert seen >= 5
 
 
+def test_blocks_outside_the_rectangle(gpu_ctx, oracle, rt, plane_mesh):
+    """k_cull blocks (64 tiles) that lie wholly outside the root box's screen rectangle fill their region row-major and
+    write no masks (k_compact learns from the block prefixes that they list nothing): images large enough to have such blocks
+    on every side of a small object, widths that are / are not multiples of 4 and 8, all three outputs, two frames in a
+    row from one context (the second smaller: stale masks of the first must not be read)."""
+    ref_b = _scene(gpu_ctx, oracle, plane_mesh)
+    for (w, h), view in (((1283, 517), dict(cam_pos=(0.3, -0.2, 4.0), rot_deg=(-90.0, 20.0, 0.0))),
+                         ((1280, 520), dict(cam_pos=(-0.4, 0.3, 3.0), rot_deg=(-60.0, 0.0, 30.0))),
+                         ((644, 260), dict(cam_pos=(0.0, 0.0, 1.3), rot_deg=(-90.0, 0.0, 0.0), scale=(2.5, 2.5, 2.5)))):
+        U = rt.make_uniforms(w, h, **view)
+        out, st = gpu_ctx.render(U, rt.render_opts(mode=rt.MODE_SHADOW, flags=rt.FLAG_COUNT_WORK))
+        ref, rst = oracle.render(ref_b["nodes"], ref_b["tri_pos"], ref_b["tri_nor"], U, mode=1, n_threads=8)
+        for k in ("rgba8", "hit_tri", "hit_t"):
+            assert np.array_equal(out[k], ref[k]), f"{w}x{h}: {k}"
+        for k in COUNT_KEYS:
+            assert st[k] == rst[k], f"{w}x{h} {k}: gpu {st[k]} vs oracle {rst[k]}"
+        hit = ref["hit_tri"] != 0xFFFFFFFF
+        assert hit.any() and hit.mean() < 0.5
+
+
 def test_coherent_scheduling_changes_order_only(gpu_ctx, oracle, rt, plane_mesh):
     """Frame-coherent scheduling: frames 2, 3, ... of a view are traced in last frame's cost order (hot pixels first, one
     class per wavefront).  Outputs and work counters must not depend on it: same view repeated, a camera cut with stale
